@@ -1,0 +1,74 @@
+"""ctypes binding of libcsm_hip.so (C ABI: include/csm_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback behind these calls.  Importing this module
+without the built library raises; calling an op without a gfx950 device raises ``CsmHipError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
+
+
+class CsmHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` (or `make -C csm-train-pytorch_amd/csrc`). "
+        "The CSM MI355X path has no fallback implementation."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+_p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+_SIGS = {
+    "csm_abi_version": ([], _i),
+    "csm_last_error": ([], C.c_char_p),
+    "csm_device_check": ([_i], _i),
+    "csm_gemm_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _ll, _ll, _ll, _ll, _p], _i),
+    "csm_rmsnorm_fwd": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
+    "csm_rmsnorm_bwd_blocks": ([], _i),
+    "csm_rmsnorm_bwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _p], _i),
+    "csm_colsum_bf16": ([_p, _i, _i, _p, _i, _p], _i),
+    "csm_rope": ([_p, _p, _p, _ll, _i, _i, _i, _i, _i, _p], _i),
+    "csm_attn_fwd": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "csm_attn_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "csm_swiglu_fwd": ([_p, _p, _ll, _i, _p], _i),
+    "csm_swiglu_bwd": ([_p, _p, _p, _ll, _i, _p], _i),
+    "csm_embed_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
+    "csm_embed_bwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
+    "csm_decoder_input_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
+    "csm_decoder_input_bwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
+    "csm_ce_fwd_bwd": ([_p, _p, _p, _p, _ll, _i, _i, _i, _f, _p], _i),
+    "csm_reduce_sum_f32": ([_p, _ll, _f, _p, _p], _i),
+    "csm_sumsq_blocks": ([], _i),
+    "csm_sumsq_bf16": ([_p, _ll, _p, _p], _i),
+    "csm_clip_coef": ([_p, _i, _f, _p, _p], _i),
+    "csm_adamw_step": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _p], _i),
+    "csm_f32_to_bf16": ([_p, _p, _ll, _i, _p], _i),
+    "csm_add_f32_into_bf16": ([_p, _p, _ll, _p], _i),
+    "csm_sample_topk": ([_p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
+    "csm_rvq_encode": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "csm_rvq_decode": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
+}
+
+for _name, (_args, _res) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _fn.argtypes = _args
+    _fn.restype = _res
+
+EXPORTS = tuple(_SIGS)
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.csm_last_error().decode("utf-8", "replace")
+        raise CsmHipError(f"{what or 'libcsm_hip'} failed (code {rc}): {msg}")
+
+
+def require_device(device_index: int = 0) -> None:
+    """Raise unless a gfx950 GPU is visible - the product path never degrades to a CPU implementation."""
+    check(lib.csm_device_check(int(device_index)), "csm_device_check")

@@ -1,0 +1,204 @@
+"""Torch-tensor front end of the C ABI: shape/dtype checks on the host, raw pointers + the current stream below.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic op is a hand-written gfx950 kernel.
+"""
+from typing import Optional
+
+import torch
+
+from . import check, lib
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, dtype=BF16):
+    """2-D row-major view with unit inner stride -> (ptr, rows, cols, ld)."""
+    assert t.is_cuda and t.dtype == dtype and t.dim() == 2 and t.stride(1) == 1, (t.dtype, t.shape, t.stride())
+    return t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)
+
+
+def gemm(A, B, C, R=None, transA=False, transB=False, alpha=1.0, batch=1, sA=0, sB=0, sC=0, sR=0):
+    """C[M,N] = alpha * opA(A) . opB(B)^T (+ R).  A: [M,K] (or [K,M] if transA); B: [N,K] (or [K,N] if transB)."""
+    pa, a0, a1, lda = _mat(A)
+    pb, b0, b1, ldb = _mat(B)
+    M, K = (a1, a0) if transA else (a0, a1)
+    N, Kb = (b1, b0) if transB else (b0, b1)
+    assert K == Kb, (A.shape, B.shape, transA, transB)
+    out_f32 = C.dtype == torch.float32
+    pc, c0, c1, ldc = _mat(C, C.dtype)
+    assert (c0, c1) == (M, N), (C.shape, M, N)
+    pr, ldr = None, 0
+    if R is not None:
+        pr, r0, r1, ldr = _mat(R)
+        assert (r0, r1) == (M, N)
+    check(lib.csm_gemm_bf16(pa, pb, pc, pr, M, N, K, lda, ldb, ldc, ldr, int(transA), int(transB), int(out_f32),
+                            float(alpha), batch, sA, sB, sC, sR, _stream()), "csm_gemm_bf16")
+    return C
+
+
+def linear_fwd(x, w, out, residual=None, alpha=1.0):
+    """out[M,N] = x[M,K] w[N,K]^T (+ residual)."""
+    return gemm(x, w, out, residual, False, False, alpha)
+
+
+def linear_dx(dy, w, out, residual=None, alpha=1.0):
+    """out[M,K] = dy[M,N] w[N,K] (+ residual)."""
+    return gemm(dy, w, out, residual, False, True, alpha)
+
+
+def linear_dw(dy, x, out, accumulate=False, alpha=1.0):
+    """out[N,K] (+)= dy[M,N]^T x[M,K]."""
+    return gemm(dy, x, out, out if accumulate else None, True, True, alpha)
+
+
+def rmsnorm_fwd(x, scale, y, rstd, eps=1e-5):
+    M, D = x.shape
+    check(lib.csm_rmsnorm_fwd(x.data_ptr(), scale.data_ptr(), y.data_ptr(), _ptr(rstd), M, D, eps, _stream()), "csm_rmsnorm_fwd")
+    return y
+
+
+def rmsnorm_bwd(x, scale, rstd, dy, dx, dres=None, dscale_partials=None):
+    M, D = x.shape
+    check(lib.csm_rmsnorm_bwd(x.data_ptr(), scale.data_ptr(), rstd.data_ptr(), dy.data_ptr(), _ptr(dres), dx.data_ptr(),
+                              _ptr(dscale_partials), M, D, _stream()), "csm_rmsnorm_bwd")
+    return dx
+
+
+def colsum_bf16(partials, dst, accumulate=False):
+    rows, D = partials.shape
+    check(lib.csm_colsum_bf16(partials.data_ptr(), rows, D, dst.data_ptr(), int(accumulate), _stream()), "csm_colsum_bf16")
+
+
+def rope(qkv, table, S, n_heads_qk, head_dim, pos=None, inverse=False):
+    M, ld = qkv.shape
+    assert table.dtype == torch.float32 and table.is_contiguous()
+    check(lib.csm_rope(qkv.data_ptr(), table.data_ptr(), _ptr(pos), M, S, n_heads_qk, head_dim, qkv.stride(0), int(inverse),
+                       _stream()), "csm_rope")
+    return qkv
+
+
+def attn_fwd(qkv, out, lse, B, S, H, KV, HD):
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (B * S, (H + 2 * KV) * HD)
+    check(lib.csm_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, KV, HD, _stream()), "csm_attn_fwd")
+    return out
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, S, H, KV, HD):
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    check(lib.csm_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                           delta_ws.data_ptr(), B, S, H, KV, HD, _stream()), "csm_attn_bwd")
+    return dqkv
+
+
+def swiglu_fwd(gu, out):
+    M, F2 = gu.shape
+    check(lib.csm_swiglu_fwd(gu.data_ptr(), out.data_ptr(), M, F2 // 2, _stream()), "csm_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu, dout, dgu):
+    M, F2 = gu.shape
+    check(lib.csm_swiglu_bwd(gu.data_ptr(), dout.data_ptr(), dgu.data_ptr(), M, F2 // 2, _stream()), "csm_swiglu_bwd")
+    return dgu
+
+
+def embed_fwd(tokens, mask_u8, text_emb, audio_emb, out, audio_vocab):
+    M, K1 = tokens.shape
+    assert tokens.dtype == torch.int64 and mask_u8.dtype == torch.uint8 and tokens.is_contiguous() and mask_u8.is_contiguous()
+    check(lib.csm_embed_fwd(tokens.data_ptr(), mask_u8.data_ptr(), text_emb.data_ptr(), audio_emb.data_ptr(), out.data_ptr(),
+                            M, K1 - 1, out.shape[1], audio_vocab, _stream()), "csm_embed_fwd")
+    return out
+
+
+def embed_bwd(tokens, mask_u8, dh, d_text_f32, d_audio_f32, audio_vocab):
+    M, K1 = tokens.shape
+    check(lib.csm_embed_bwd(tokens.data_ptr(), mask_u8.data_ptr(), dh.data_ptr(), d_text_f32.data_ptr(),
+                            d_audio_f32.data_ptr(), M, K1 - 1, dh.shape[1], audio_vocab, _stream()), "csm_embed_bwd")
+
+
+def decoder_input_fwd(hidden, rows_i32, codes, audio_emb, out, audio_vocab):
+    N, K = codes.shape
+    assert rows_i32.dtype == torch.int32 and codes.dtype == torch.int64 and codes.is_contiguous()
+    check(lib.csm_decoder_input_fwd(hidden.data_ptr(), rows_i32.data_ptr(), codes.data_ptr(), audio_emb.data_ptr(),
+                                    out.data_ptr(), N, K, hidden.shape[1], audio_vocab, _stream()), "csm_decoder_input_fwd")
+    return out
+
+
+def decoder_input_bwd(dseq, rows_i32, codes, d_hidden_f32, d_audio_f32, audio_vocab):
+    N, K = codes.shape
+    check(lib.csm_decoder_input_bwd(dseq.data_ptr(), rows_i32.data_ptr(), codes.data_ptr(), d_hidden_f32.data_ptr(),
+                                    _ptr(d_audio_f32), N, K, d_hidden_f32.shape[1], audio_vocab, _stream()),
+          "csm_decoder_input_bwd")
+
+
+def ce_fwd_bwd(logits_f32, targets, loss_rows, dlogits, V, grad_scale):
+    R, ldl = logits_f32.shape[0], logits_f32.stride(0)
+    assert logits_f32.dtype == torch.float32 and targets.dtype == torch.int64 and targets.is_contiguous()
+    ldd = dlogits.stride(0) if dlogits is not None else 0
+    check(lib.csm_ce_fwd_bwd(logits_f32.data_ptr(), targets.data_ptr(), loss_rows.data_ptr(), _ptr(dlogits), R, V, ldl, ldd,
+                             float(grad_scale), _stream()), "csm_ce_fwd_bwd")
+
+
+def reduce_sum(x_f32, out_f32, scale=1.0):
+    check(lib.csm_reduce_sum_f32(x_f32.data_ptr(), x_f32.numel(), float(scale), out_f32.data_ptr(), _stream()), "csm_reduce_sum_f32")
+
+
+def sumsq_blocks() -> int:
+    return lib.csm_sumsq_blocks()
+
+
+def sumsq_bf16(g, partials):
+    check(lib.csm_sumsq_bf16(g.data_ptr(), g.numel(), partials.data_ptr(), _stream()), "csm_sumsq_bf16")
+
+
+def clip_coef(partials, max_norm, norm_and_coef):
+    check(lib.csm_clip_coef(partials.data_ptr(), partials.numel(), float(max_norm), norm_and_coef.data_ptr(), _stream()), "csm_clip_coef")
+
+
+def adamw_step(master, m, v, param, grad, lr, beta1, beta2, eps, wd, step, norm_and_coef=None, grad_mul=1.0):
+    n = master.numel()
+    assert master.dtype == torch.float32 and param.dtype == BF16 and grad.dtype == BF16 and param.numel() == n == grad.numel()
+    check(lib.csm_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), param.data_ptr(), grad.data_ptr(), n, lr, beta1,
+                             beta2, eps, wd, int(step), _ptr(norm_and_coef), float(grad_mul), _stream()), "csm_adamw_step")
+
+
+def f32_to_bf16(src, dst, accumulate=False):
+    check(lib.csm_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), int(accumulate), _stream()), "csm_f32_to_bf16")
+
+
+def add_f32_into_bf16(a, b):
+    check(lib.csm_add_f32_into_bf16(a.data_ptr(), b.data_ptr(), a.numel(), _stream()), "csm_add_f32_into_bf16")
+
+
+def sample_topk(logits_f32, q_f32, out_i32, topk, temperature, V=None):
+    rows = logits_f32.shape[0]
+    V = V or logits_f32.shape[1]
+    assert q_f32.is_contiguous() and q_f32.shape == (rows, V)
+    check(lib.csm_sample_topk(logits_f32.data_ptr(), q_f32.data_ptr(), out_i32.data_ptr(), rows, V, logits_f32.stride(0),
+                              int(topk), float(temperature), _stream()), "csm_sample_topk")
+    return out_i32
+
+
+def rvq_encode(x_f32, codebooks_f32, codes_i64, n_semantic=1):
+    T, D = x_f32.shape
+    K, Cn, D2 = codebooks_f32.shape
+    assert D == D2 and codes_i64.shape == (K, T) and x_f32.is_contiguous() and codebooks_f32.is_contiguous()
+    check(lib.csm_rvq_encode(x_f32.data_ptr(), codebooks_f32.data_ptr(), codes_i64.data_ptr(), T, K, Cn, D, n_semantic,
+                             _stream()), "csm_rvq_encode")
+    return codes_i64
+
+
+def rvq_decode(codes_i64, codebooks_f32, out_f32):
+    K, T = codes_i64.shape
+    _, Cn, D = codebooks_f32.shape
+    check(lib.csm_rvq_decode(codes_i64.data_ptr(), codebooks_f32.data_ptr(), out_f32.data_ptr(), T, K, Cn, D, _stream()),
+          "csm_rvq_decode")
+    return out_f32

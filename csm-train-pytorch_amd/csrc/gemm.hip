@@ -1,0 +1,244 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = alpha * opA(A) . opB(B)^T (+ R)
+//
+//   TA == 0 : A is [M][K] row-major (K contiguous, "kc")      TA == 1 : A is [K][M] row-major ("ks")
+//   TB == 0 : B is [N][K] row-major (torch Linear weight)     TB == 1 : B is [K][N] row-major
+//
+// so one kernel family covers the three products of a Linear layer without materialised transposes:
+//   forward  Y  = X  W^T      (TA=0,TB=0)      A=X[M,K]    B=W[N,K]
+//   dgrad    dX = dY W        (TA=0,TB=1)      A=dY[M,N']  B=W[N',K'] read as [K=N'][N=K']
+//   wgrad    dW = dY^T X      (TA=1,TB=1)      A=dY[M',N'] read as [K=M'][M=N'],  B=X[M',K'] as [K=M'][N=K']
+//
+// Replaces the torchtune nn.Linear calls configured at reference src/csm/models/model.py:13-42 and
+// the projection / heads at src/csm/models/model.py:124-126,172,184,187.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 16 accumulators of
+// mfma_f32_16x16x32_bf16).  LDS: 2 x (16 KiB A + 16 KiB B) double buffer.  Global->register->LDS
+// staging one tile ahead; one barrier per K-tile.  LDS images are XOR-swizzled so that both the
+// ds_read_b128 row fragments (kc) and the ds_read_b64_tr_b16 transposed fragments (ks) are
+// bank-conflict free:
+//   kc image [128 rows][64 k]   : 16-B chunk c of row r lives at chunk  c ^ (r & 7)
+//   ks image [64 k][128 cols]   : 32-B slot  s of k-row r lives at slot s ^ (r & 7)
+// The MFMA is issued with the operands swapped (D = Btile . Atile^T) so every lane ends up with
+// four CONSECUTIVE output columns of one row: 8-byte bf16 / 16-byte fp32 stores, no LDS epilogue.
+// Workgroup ids are remapped so that each XCD (private 4 MiB L2) walks a contiguous, GROUP_M-rastered
+// run of tiles.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* R;
+    int M, N, K, lda, ldb, ldc, ldr;
+    long long sA, sB, sC, sR;  // batch strides in elements
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+// ---- staging: each thread moves 4 x 16 B per operand per K-tile --------------------------------
+template <int T>
+__device__ __forceinline__ void stage_load(const bf16_t* __restrict__ P, int ld, int rows /*M or N*/, int K,
+                                           int row0, int k0, U4 (&reg)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        U4 v = {0u, 0u, 0u, 0u};
+        if (T == 0) {
+            const int r = idx >> 3, c = idx & 7;
+            int gr = row0 + r;
+            gr = gr < rows ? gr : rows - 1;                 // clamp: garbage rows are masked at the store
+            const int gk = k0 + c * 8;
+            if (gk < K) v = *reinterpret_cast<const U4*>(P + (size_t)gr * ld + gk);
+        } else {
+            const int kr = idx >> 4, c = idx & 15;
+            const int gk = k0 + kr, gc = row0 + c * 8;
+            if (gk < K && gc < rows) v = *reinterpret_cast<const U4*>(P + (size_t)gk * ld + gc);
+        }
+        reg[i] = v;
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void stage_store(char* lds, const U4 (&reg)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        int off;
+        if (T == 0) {
+            const int r = idx >> 3, c = idx & 7;
+            off = r * 128 + ((c ^ (r & 7)) << 4);
+        } else {
+            const int kr = idx >> 4, c = idx & 15;
+            off = kr * 256 + ((((c >> 1) ^ (kr & 7)) << 5) | ((c & 1) << 4));
+        }
+        *reinterpret_cast<U4*>(lds + off) = reg[i];
+    }
+}
+
+// fragment of 16 tile-rows starting at r0 for k-step ks (32 deep) -> lane holds row (lane&15), k = 8*(lane>>4)+j
+template <int T>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int ks, int lane) {
+    if (T == 0) {
+        const int r = r0 + (lane & 15);
+        const int c = ks * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ (r & 7)) << 4));
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int kr0 = ks * 32 + 8 * g + q;       // rows kr0 (+4 for the second half)
+        const int slot = r0 >> 4;
+        const int kr1 = kr0 + 4;
+        bf16x4 lo = lds_read_tr16(lds + kr0 * 256 + ((slot ^ (kr0 & 7)) << 5) + p * 8);
+        bf16x4 hi = lds_read_tr16(lds + kr1 * 256 + ((slot ^ (kr1 & 7)) << 5) + p * 8);
+        return cat4(lo, hi);
+    }
+}
+
+template <int TA, int TB, typename OutT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- XCD-aware, GROUP_M-rastered tile id -------------------------------------------------
+    const int nwg = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (id % per_group) % gsz;
+    const int tn = (id % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int bz = blockIdx.z;
+    const bf16_t* A = g.A + (size_t)bz * g.sA;
+    const bf16_t* B = g.B + (size_t)bz * g.sB;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto ldsA = [&](int b) { return smem + b * 2 * TILE_BYTES; };
+    auto ldsB = [&](int b) { return smem + b * 2 * TILE_BYTES + TILE_BYTES; };
+
+    U4 ra[4], rb[4];
+    const int nt = (g.K + BK - 1) / BK;
+    stage_load<TA>(A, g.lda, g.M, g.K, m0, 0, ra);
+    stage_load<TB>(B, g.ldb, g.N, g.K, n0, 0, rb);
+    stage_store<TA>(ldsA(0), ra);
+    stage_store<TB>(ldsB(0), rb);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            stage_load<TA>(A, g.lda, g.M, g.K, m0, (t + 1) * BK, ra);
+            stage_load<TB>(B, g.ldb, g.N, g.K, n0, (t + 1) * BK, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = load_frag<TA>(ldsA(cur), wm0 + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = load_frag<TB>(ldsB(cur), wn0 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) {
+            stage_store<TA>(ldsA(cur ^ 1), ra);
+            stage_store<TB>(ldsB(cur ^ 1), rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] per 16x16 tile ----------
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
+    const bf16_t* R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!R || (g.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm0 + 16 * i + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn0 + 16 * j + 4 * (lane >> 4);
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha,
+                          acc[i][j][3] * g.alpha};
+            if (vec_ok && n + 3 < g.N) {
+                if (R) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + (size_t)m * g.ldr + n);
+                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                }
+                if constexpr (sizeof(OutT) == 2) {
+                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = o;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                for (int e = 0; e < 4 && n + e < g.N; ++e) {
+                    float x = v[e];
+                    if (R) x += bf2f(R[(size_t)m * g.ldr + n + e]);
+                    if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(C)[(size_t)m * g.ldc + n + e] = f2bf(x);
+                    else reinterpret_cast<float*>(C)[(size_t)m * g.ldc + n + e] = x;
+                }
+            }
+        }
+    }
+}
+
+template <int TA, int TB>
+int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
+    dim3 grid(g.tiles_m * g.tiles_n, 1, batch), block(256);
+    const size_t lds = 4 * TILE_BYTES;
+    if (out_f32) hipLaunchKernelGGL((gemm_kernel<TA, TB, float>), grid, block, lds, stream, g);
+    else hipLaunchKernelGGL((gemm_kernel<TA, TB, bf16_t>), grid, block, lds, stream, g);
+    CSM_CHECK_LAUNCH("csm_gemm_bf16");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                             int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
+                             long long strideA, long long strideB, long long strideC, long long strideR,
+                             hipStream_t stream) {
+    CSM_REQUIRE(A && B && C, "csm_gemm_bf16: null operand");
+    CSM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "csm_gemm_bf16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    CSM_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "csm_gemm_bf16: lda/ldb must be multiples of 8 (lda=%d ldb=%d)", lda, ldb);
+    CSM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "csm_gemm_bf16: A/B must be 16-byte aligned");
+    CSM_REQUIRE((strideA & 7) == 0 && (strideB & 7) == 0, "csm_gemm_bf16: batch strides of A/B must be multiples of 8");
+    if (!transA) CSM_REQUIRE((K & 7) == 0, "csm_gemm_bf16: K must be a multiple of 8 when A is [M][K] (K=%d)", K);
+    else CSM_REQUIRE((M & 7) == 0, "csm_gemm_bf16: M must be a multiple of 8 when A is [K][M] (M=%d)", M);
+    if (!transB) CSM_REQUIRE((K & 7) == 0, "csm_gemm_bf16: K must be a multiple of 8 when B is [N][K] (K=%d)", K);
+    else CSM_REQUIRE((N & 7) == 0, "csm_gemm_bf16: N must be a multiple of 8 when B is [K][N] (N=%d)", N);
+    CSM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, "csm_gemm_bf16: leading dimension too small");
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sR = strideR;
+    g.alpha = alpha;
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    if (!transA && !transB) return launch<0, 0>(g, out_f32, batch, stream);
+    if (!transA && transB) return launch<0, 1>(g, out_f32, batch, stream);
+    if (transA && transB) return launch<1, 1>(g, out_f32, batch, stream);
+    return launch<1, 0>(g, out_f32, batch, stream);
+}

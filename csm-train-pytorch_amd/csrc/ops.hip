@@ -1,0 +1,605 @@
+// HBM-bound kernels of the CSM train step for gfx950: RMSNorm, RoPE, SwiGLU, masked multi-codebook embedding,
+// fused softmax-cross-entropy, gradient-norm / clip and AdamW.  All of them move 16 bytes per lane per access
+// and reduce with 64-lane shuffles; none stages through LDS except for block-level scalars.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ RMSNorm
+// torchtune RMSNorm (appendix A of SURVEY.md; built by reference src/csm/models/model.py:13-42):
+//   y = x * rsqrt(mean(x^2) + eps) * scale, statistics in fp32.  One wave per row, row held in registers.
+template <int NC>  // 16-B chunks per lane: D <= NC*512
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd, int M, int D,
+                                                          float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int nchunk = D >> 3;
+    for (long long row = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += (long long)gridDim.x * wpb) {
+        U4 v[NC];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (U4){0u, 0u, 0u, 0u};
+            if (c < nchunk) v[i] = *reinterpret_cast<const U4*>(x + (size_t)row * D + c * 8);
+            float f[8];
+            unpack8(v[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)D + eps);
+        if (lane == 0 && rstd) rstd[row] = r;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float f[8], s[8];
+                unpack8(v[i], f);
+                unpack8(*reinterpret_cast<const U4*>(w + c * 8), s);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = f[j] * r * s[j];
+                *reinterpret_cast<U4*>(y + (size_t)row * D + c * 8) = pack8(f);
+            }
+        }
+    }
+}
+
+// dx = rstd * (dy*w) - x * rstd^3/D * sum(dy*w*x) (+ dres);  per-block partial of dw = sum_rows dy * x * rstd
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          const float* __restrict__ rstd, const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dw_acc, int M, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem_dw[];
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int nchunk = D >> 3;
+    float dwl[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwl[i][j] = 0.f;
+    float ws[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        U4 t = {0u, 0u, 0u, 0u};
+        if (c < nchunk) t = *reinterpret_cast<const U4*>(w + c * 8);
+        unpack8(t, ws[i]);
+    }
+    for (long long row = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += (long long)gridDim.x * wpb) {
+        float xs[NC][8], gs[NC][8];
+        float dot = 0.f;
+        const float r = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            U4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+            if (c < nchunk) {
+                a = *reinterpret_cast<const U4*>(x + (size_t)row * D + c * 8);
+                b = *reinterpret_cast<const U4*>(dy + (size_t)row * D + c * 8);
+            }
+            unpack8(a, xs[i]);
+            unpack8(b, gs[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (dw_acc) dwl[i][j] += gs[i][j] * xs[i][j] * r;
+                gs[i][j] *= ws[i][j];
+                dot += gs[i][j] * xs[i][j];
+            }
+        }
+        dot = wave_sum(dot);
+        const float k = r * r * r * dot / (float)D;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = r * gs[i][j] - k * xs[i][j];
+                if (dres) {
+                    float rr[8];
+                    unpack8(*reinterpret_cast<const U4*>(dres + (size_t)row * D + c * 8), rr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += rr[j];
+                }
+                *reinterpret_cast<U4*>(dx + (size_t)row * D + c * 8) = pack8(o);
+            }
+        }
+    }
+    if (dw_acc) {
+        // block-level reduction through LDS, then one coalesced partial row per block: dw_acc[blockIdx.x][D]
+        float* red = reinterpret_cast<float*>(smem_dw);
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[wv * D + c * 8 + j] = dwl[i][j];
+            }
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < D; col += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < wpb; ++k) t += red[k * D + col];
+            dw_acc[(size_t)blockIdx.x * D + col] = t;
+        }
+    }
+}
+
+// dst(bf16)[col] (+)= sum_r partials[r][col]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int rows, int D, bf16_t* __restrict__ dst,
+                                                     int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= D) return;
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += partials[(size_t)r * D + col];
+    if (accumulate) t += bf2f(dst[col]);
+    dst[col] = f2bf(t);
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE
+// torchtune Llama3ScaledRoPE on the fused qkv buffer, in place: interleaved pairs (2i, 2i+1) of every q and k
+// head rotated by pos*theta'_i (table [P][hd/2][2] = cos,sin fp32, built on the host exactly as the oracle does).
+// inverse = 1 applies the transpose rotation (backward).
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ table,
+                                                   const int* __restrict__ pos, long long M, int S, int nheads /*H+KV*/,
+                                                   int hd, int ld, int inverse) {
+    const int cph = hd >> 3;                         // chunks per head
+    const long long per_row = (long long)nheads * cph;
+    const long long total = M * per_row;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / per_row;
+        const int rem = (int)(idx % per_row);
+        const int head = rem / cph, c = rem % cph;
+        const int p = pos ? pos[row] : (int)(row % S);
+        bf16_t* ptr = qkv + (size_t)row * ld + head * hd + c * 8;
+        float f[8], o[8];
+        unpack8(*reinterpret_cast<const U4*>(ptr), f);
+        const float4 t0 = *reinterpret_cast<const float4*>(table + ((size_t)p * (hd >> 1) + c * 4) * 2);
+        const float4 t1 = *reinterpret_cast<const float4*>(table + ((size_t)p * (hd >> 1) + c * 4) * 2 + 4);
+        const float cs[4] = {t0.x, t0.z, t1.x, t1.z};
+        float sn[4] = {t0.y, t0.w, t1.y, t1.w};
+        if (inverse) { sn[0] = -sn[0]; sn[1] = -sn[1]; sn[2] = -sn[2]; sn[3] = -sn[3]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = f[2 * i] * cs[i] - f[2 * i + 1] * sn[i];
+            o[2 * i + 1] = f[2 * i + 1] * cs[i] + f[2 * i] * sn[i];
+        }
+        *reinterpret_cast<U4*>(ptr) = pack8(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SwiGLU
+// torchtune FeedForward: w2(silu(w1 x) * w3 x).  gu = [gate | up] ([M][2F]) from the fused w1/w3 GEMM.
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long long M,
+                                                         int F) {
+    const int cpr = F >> 3;
+    const long long total = M * cpr;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / cpr;
+        const int c = (int)(idx % cpr);
+        float g[8], u[8], o[8];
+        unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + c * 8), g);
+        unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + F + c * 8), u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+        *reinterpret_cast<U4*>(out + (size_t)row * F + c * 8) = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dout,
+                                                         bf16_t* __restrict__ dgu, long long M, int F) {
+    const int cpr = F >> 3;
+    const long long total = M * cpr;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / cpr;
+        const int c = (int)(idx % cpr);
+        float g[8], u[8], d[8], dg[8], du[8];
+        unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + c * 8), g);
+        unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + F + c * 8), u);
+        unpack8(*reinterpret_cast<const U4*>(dout + (size_t)row * F + c * 8), d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sg = 1.f / (1.f + __expf(-g[j]));
+            const float silu = g[j] * sg;
+            du[j] = d[j] * silu;
+            dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
+        }
+        *reinterpret_cast<U4*>(dgu + (size_t)row * 2 * F + c * 8) = pack8(dg);
+        *reinterpret_cast<U4*>(dgu + (size_t)row * 2 * F + F + c * 8) = pack8(du);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+// reference src/csm/models/model.py:202-217 + mask-mul-sum src/csm/training/utils.py:85-87:
+//   h[row] = sum over live slots c of  (c < K ? audio_emb[tok + c*V_a] : text_emb[tok]).   One block per row.
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ tokens, const uint8_t* __restrict__ mask,
+                                                        const bf16_t* __restrict__ text_emb, const bf16_t* __restrict__ audio_emb,
+                                                        bf16_t* __restrict__ out, int K, int D, int audio_vocab) {
+    const long long row = blockIdx.x;
+    const long long* tok = tokens + row * (K + 1);
+    const uint8_t* mk = mask + row * (K + 1);
+    for (int c0 = threadIdx.x * 8; c0 < D; c0 += blockDim.x * 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s <= K; ++s) {
+            if (!mk[s]) continue;
+            const bf16_t* src = (s < K) ? audio_emb + ((size_t)tok[s] + (size_t)s * audio_vocab) * D : text_emb + (size_t)tok[s] * D;
+            float f[8];
+            unpack8(*reinterpret_cast<const U4*>(src + c0), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+        *reinterpret_cast<U4*>(out + (size_t)row * D + c0) = pack8(acc);
+    }
+}
+
+// scatter-add of dh rows into fp32 embedding-gradient scratch; lane l adds column l + 64*j: 256 contiguous
+// bytes per wave-instruction, the shape global float atomics run fastest at.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tokens, const uint8_t* __restrict__ mask,
+                                                        const bf16_t* __restrict__ dh, float* __restrict__ d_text,
+                                                        float* __restrict__ d_audio, int K, int D, int audio_vocab) {
+    const long long row = blockIdx.x;
+    const long long* tok = tokens + row * (K + 1);
+    const uint8_t* mk = mask + row * (K + 1);
+    for (int col = threadIdx.x; col < D; col += blockDim.x) {
+        const float g = bf2f(dh[(size_t)row * D + col]);
+        for (int s = 0; s <= K; ++s) {
+            if (!mk[s]) continue;
+            float* dst = (s < K) ? d_audio + ((size_t)tok[s] + (size_t)s * audio_vocab) * D : d_text + (size_t)tok[s] * D;
+            atomicAdd(dst + col, g);
+        }
+    }
+}
+
+// build the depth-decoder input rows [N][K][D]: position 0 = backbone state h[row], position i>=1 = audio_emb of
+// code i-1 of the target frame (teacher forcing of reference src/csm/models/model.py:175-189).
+__global__ __launch_bounds__(256) void decoder_input_kernel(const bf16_t* __restrict__ hidden, const int* __restrict__ rows,
+                                                            const long long* __restrict__ codes /*[N][K]*/,
+                                                            const bf16_t* __restrict__ audio_emb, bf16_t* __restrict__ out,
+                                                            int K, int D, int audio_vocab) {
+    const long long n = blockIdx.x / K;
+    const int i = blockIdx.x % K;
+    const bf16_t* src = (i == 0) ? hidden + (size_t)rows[n] * D
+                                 : audio_emb + ((size_t)codes[n * K + i - 1] + (size_t)(i - 1) * audio_vocab) * D;
+    for (int c0 = threadIdx.x * 8; c0 < D; c0 += blockDim.x * 8)
+        *reinterpret_cast<U4*>(out + ((size_t)n * K + i) * D + c0) = *reinterpret_cast<const U4*>(src + c0);
+}
+
+// backward of the above: position 0 -> atomically into fp32 d_hidden scratch rows, positions >=1 -> fp32 d_audio rows
+__global__ __launch_bounds__(256) void decoder_input_bwd_kernel(const bf16_t* __restrict__ dseq, const int* __restrict__ rows,
+                                                                const long long* __restrict__ codes, float* __restrict__ d_hidden,
+                                                                float* __restrict__ d_audio, int K, int D, int audio_vocab) {
+    const long long n = blockIdx.x / K;
+    const int i = blockIdx.x % K;
+    float* dst = (i == 0) ? d_hidden + (size_t)rows[n] * D
+                          : (d_audio ? d_audio + ((size_t)codes[n * K + i - 1] + (size_t)(i - 1) * audio_vocab) * D : nullptr);
+    if (!dst) return;
+    for (int col = threadIdx.x; col < D; col += blockDim.x) atomicAdd(dst + col, bf2f(dseq[((size_t)n * K + i) * D + col]));
+}
+
+// ------------------------------------------------------------------------------------------------ cross-entropy
+// F.cross_entropy(mean) of reference src/csm/training/utils.py:102-105, fused with its backward:
+// loss_row = logsumexp(x) - x[t];  dlogits = (softmax(x) - onehot(t)) * gscale, bf16, pad columns zeroed.
+// target < 0 marks a row that is not part of the loss (last position of each sequence).
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const long long* __restrict__ targets,
+                                                 float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, int V, int ldl,
+                                                 int ldd, float gscale) {
+    __shared__ float red[16];
+    const long long row = blockIdx.x;
+    const float* x = logits + (size_t)row * ldl;
+    const long long t = targets[row];
+    if (t < 0) {
+        if (threadIdx.x == 0) loss_rows[row] = 0.f;
+        if (dlogits)
+            for (int c = threadIdx.x; c < ldd; c += blockDim.x) dlogits[(size_t)row * ldd + c] = 0;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) mx = fmaxf(mx, x[c]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) sum += __expf(x[c] - mx);
+    sum = block_sum(sum, red);
+    const float lse = mx + logf(sum);
+    if (threadIdx.x == 0) loss_rows[row] = lse - x[t];
+    if (dlogits) {
+        for (int c = threadIdx.x; c < ldd; c += blockDim.x) {
+            float g = 0.f;
+            if (c < V) g = (__expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * gscale;
+            dlogits[(size_t)row * ldd + c] = f2bf(g);
+        }
+    }
+}
+
+// deterministic single-block sum: out[0] = scale * sum(x[0..n))
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, long long n, float scale,
+                                                          float* __restrict__ out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) acc += x[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = acc * scale;
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+// sum of squares of a bf16 gradient range -> one fp32 partial per block (deterministic two-stage reduction)
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ g, long long n, float* __restrict__ partials) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    const long long nvec = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float f[8];
+        unpack8(*reinterpret_cast<const U4*>(g + i * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += f[j] * f[j];
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (nvec << 3) + threadIdx.x; i < n; i += blockDim.x) { const float f = bf2f(g[i]); acc += f * f; }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// norm = sqrt(sum partials); coef = min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_, reference
+// src/csm/training/trainer.py:271-274).  max_norm <= 0 disables clipping.  out[0] = norm, out[1] = coef.
+__global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ partials, int n, float max_norm,
+                                                         float* __restrict__ out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(acc);
+        out[0] = norm;
+        out[1] = (max_norm > 0.f) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    }
+}
+
+// torch.optim.AdamW over one contiguous parameter range: fp32 master / m / v, bf16 gradient (times the device-side
+// clip coefficient), writes the bf16 working copy.  28 B/param of HBM traffic.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ param, const bf16_t* __restrict__ grad, long long n,
+                                                    float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, const float* __restrict__ coef_ptr, float gmul) {
+    const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gmul;
+    const long long nvec = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float g[8];
+        unpack8(*reinterpret_cast<const U4*>(grad + i * 8), g);
+        float4 p0 = *reinterpret_cast<const float4*>(master + i * 8), p1 = *reinterpret_cast<const float4*>(master + i * 8 + 4);
+        float4 m0 = *reinterpret_cast<const float4*>(m + i * 8), m1 = *reinterpret_cast<const float4*>(m + i * 8 + 4);
+        float4 v0 = *reinterpret_cast<const float4*>(v + i * 8), v1 = *reinterpret_cast<const float4*>(v + i * 8 + 4);
+        float p[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = g[j] * coef;
+            p[j] *= (1.f - lr * wd);
+            mm[j] = beta1 * mm[j] + (1.f - beta1) * gj;
+            vv[j] = beta2 * vv[j] + (1.f - beta2) * gj * gj;
+            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+            p[j] -= (lr / bc1) * (mm[j] / denom);
+        }
+        *reinterpret_cast<float4*>(master + i * 8) = make_float4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<float4*>(master + i * 8 + 4) = make_float4(p[4], p[5], p[6], p[7]);
+        *reinterpret_cast<float4*>(m + i * 8) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<float4*>(m + i * 8 + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+        *reinterpret_cast<float4*>(v + i * 8) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(v + i * 8 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+        *reinterpret_cast<U4*>(param + i * 8) = pack8(p);
+    }
+}
+
+// dst(bf16) = (accumulate ? dst : 0) + src(fp32)   (embedding / norm-scale gradient scratch -> bf16 gradient arena)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n,
+                                                          int accumulate) {
+    const long long nvec = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (accumulate) {
+            float o[8];
+            unpack8(*reinterpret_cast<const U4*>(dst + i * 8), o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += o[j];
+        }
+        *reinterpret_cast<U4*>(dst + i * 8) = pack8(f);
+    }
+}
+
+// out(bf16) = a(bf16) + b(fp32)  (adds the decoder's fp32 d_hidden scratch into the backbone's output gradient)
+__global__ __launch_bounds__(256) void add_f32_kernel(bf16_t* __restrict__ a, const float* __restrict__ b, long long n) {
+    const long long nvec = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = *reinterpret_cast<const float4*>(b + i * 8), y = *reinterpret_cast<const float4*>(b + i * 8 + 4);
+        float f[8];
+        unpack8(*reinterpret_cast<const U4*>(a + i * 8), f);
+        f[0] += x.x; f[1] += x.y; f[2] += x.z; f[3] += x.w; f[4] += y.x; f[5] += y.y; f[6] += y.z; f[7] += y.w;
+        *reinterpret_cast<U4*>(a + i * 8) = pack8(f);
+    }
+}
+
+inline int grid_for(long long work_items, int block, int cap = 256 * 8) {
+    long long b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" int csm_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int M, int D, float eps,
+                               hipStream_t stream) {
+    CSM_REQUIRE(x && scale && y, "csm_rmsnorm_fwd: null pointer");
+    CSM_REQUIRE(M > 0 && D > 0 && (D & 7) == 0 && D <= 4096, "csm_rmsnorm_fwd: D=%d must be a multiple of 8 and <= 4096", D);
+    const int grid = grid_for(M, 4, 4096);
+    const int nc = (D + 511) / 512;
+#define L(NC) hipLaunchKernelGGL((rmsnorm_fwd_kernel<NC>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)scale, (bf16_t*)y, rstd, M, D, eps)
+    if (nc <= 1) L(1); else if (nc <= 2) L(2); else if (nc <= 4) L(4); else L(8);
+#undef L
+    CSM_CHECK_LAUNCH("csm_rmsnorm_fwd");
+    return 0;
+}
+
+#define CSM_RMSNORM_BWD_BLOCKS 256
+extern "C" int csm_rmsnorm_bwd_blocks(void) { return CSM_RMSNORM_BWD_BLOCKS; }
+
+// dscale_partials: [csm_rmsnorm_bwd_blocks()][D] fp32 workspace (every row is written), or NULL when the scale is frozen
+extern "C" int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rstd, const void* dy, const void* dres,
+                               void* dx, float* dscale_partials, int M, int D, hipStream_t stream) {
+    CSM_REQUIRE(x && scale && rstd && dy && dx, "csm_rmsnorm_bwd: null pointer");
+    CSM_REQUIRE(M > 0 && D > 0 && (D & 7) == 0 && D <= 4096, "csm_rmsnorm_bwd: D=%d must be a multiple of 8 and <= 4096", D);
+    const int grid = CSM_RMSNORM_BWD_BLOCKS;
+    const int nc = (D + 511) / 512;
+    const size_t lds = dscale_partials ? (size_t)4 * D * sizeof(float) : 0;
+#define L(NC) hipLaunchKernelGGL((rmsnorm_bwd_kernel<NC>), dim3(grid), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)scale, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dscale_partials, M, D)
+    if (nc <= 1) L(1); else if (nc <= 2) L(2); else if (nc <= 4) L(4); else L(8);
+#undef L
+    CSM_CHECK_LAUNCH("csm_rmsnorm_bwd");
+    return 0;
+}
+
+extern "C" int csm_colsum_bf16(const float* partials, int rows, int D, void* dst, int accumulate, hipStream_t stream) {
+    CSM_REQUIRE(partials && dst && rows > 0 && D > 0, "csm_colsum_bf16: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, partials, rows, D, (bf16_t*)dst, accumulate);
+    CSM_CHECK_LAUNCH("csm_colsum_bf16");
+    return 0;
+}
+
+extern "C" int csm_rope(void* qkv, const float* table, const int* pos, long long M, int S, int n_heads_qk, int head_dim,
+                        int ld, int inverse, hipStream_t stream) {
+    CSM_REQUIRE(qkv && table, "csm_rope: null pointer");
+    CSM_REQUIRE(M > 0 && S > 0 && n_heads_qk > 0 && (head_dim & 7) == 0 && (ld & 7) == 0, "csm_rope: bad shape");
+    const long long total = M * n_heads_qk * (head_dim >> 3);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, (bf16_t*)qkv, table, pos, M, S,
+                       n_heads_qk, head_dim, ld, inverse);
+    CSM_CHECK_LAUNCH("csm_rope");
+    return 0;
+}
+
+extern "C" int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, hipStream_t stream) {
+    CSM_REQUIRE(gu && out && M > 0 && F > 0 && (F & 7) == 0, "csm_swiglu_fwd: bad arguments");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(M * (F >> 3), 256, 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
+                       (bf16_t*)out, M, F);
+    CSM_CHECK_LAUNCH("csm_swiglu_fwd");
+    return 0;
+}
+
+extern "C" int csm_swiglu_bwd(const void* gu, const void* dout, void* dgu, long long M, int F, hipStream_t stream) {
+    CSM_REQUIRE(gu && dout && dgu && M > 0 && F > 0 && (F & 7) == 0, "csm_swiglu_bwd: bad arguments");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * (F >> 3), 256, 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
+                       (const bf16_t*)dout, (bf16_t*)dgu, M, F);
+    CSM_CHECK_LAUNCH("csm_swiglu_bwd");
+    return 0;
+}
+
+extern "C" int csm_embed_fwd(const long long* tokens, const uint8_t* mask, const void* text_emb, const void* audio_emb,
+                             void* out, long long M, int K, int D, int audio_vocab, hipStream_t stream) {
+    CSM_REQUIRE(tokens && mask && text_emb && audio_emb && out, "csm_embed_fwd: null pointer");
+    CSM_REQUIRE(M > 0 && M < (1ll << 31) && K > 0 && (D & 7) == 0, "csm_embed_fwd: bad shape");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, tokens, mask, (const bf16_t*)text_emb,
+                       (const bf16_t*)audio_emb, (bf16_t*)out, K, D, audio_vocab);
+    CSM_CHECK_LAUNCH("csm_embed_fwd");
+    return 0;
+}
+
+extern "C" int csm_embed_bwd(const long long* tokens, const uint8_t* mask, const void* dh, float* d_text, float* d_audio,
+                             long long M, int K, int D, int audio_vocab, hipStream_t stream) {
+    CSM_REQUIRE(tokens && mask && dh && d_text && d_audio, "csm_embed_bwd: null pointer");
+    CSM_REQUIRE(M > 0 && M < (1ll << 31) && K > 0, "csm_embed_bwd: bad shape");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, tokens, mask, (const bf16_t*)dh, d_text,
+                       d_audio, K, D, audio_vocab);
+    CSM_CHECK_LAUNCH("csm_embed_bwd");
+    return 0;
+}
+
+extern "C" int csm_decoder_input_fwd(const void* hidden, const int* rows, const long long* codes, const void* audio_emb,
+                                     void* out, long long N, int K, int D, int audio_vocab, hipStream_t stream) {
+    CSM_REQUIRE(hidden && rows && codes && audio_emb && out && N > 0 && N * K < (1ll << 31) && (D & 7) == 0,
+                "csm_decoder_input_fwd: bad arguments");
+    hipLaunchKernelGGL(decoder_input_kernel, dim3((unsigned)(N * K)), dim3(256), 0, stream, (const bf16_t*)hidden, rows, codes,
+                       (const bf16_t*)audio_emb, (bf16_t*)out, K, D, audio_vocab);
+    CSM_CHECK_LAUNCH("csm_decoder_input_fwd");
+    return 0;
+}
+
+extern "C" int csm_decoder_input_bwd(const void* dseq, const int* rows, const long long* codes, float* d_hidden,
+                                     float* d_audio, long long N, int K, int D, int audio_vocab, hipStream_t stream) {
+    CSM_REQUIRE(dseq && rows && codes && d_hidden && N > 0 && N * K < (1ll << 31), "csm_decoder_input_bwd: bad arguments");
+    hipLaunchKernelGGL(decoder_input_bwd_kernel, dim3((unsigned)(N * K)), dim3(256), 0, stream, (const bf16_t*)dseq, rows,
+                       codes, d_hidden, d_audio, K, D, audio_vocab);
+    CSM_CHECK_LAUNCH("csm_decoder_input_bwd");
+    return 0;
+}
+
+extern "C" int csm_ce_fwd_bwd(const float* logits, const long long* targets, float* loss_rows, void* dlogits, long long R,
+                              int V, int ldl, int ldd, float grad_scale, hipStream_t stream) {
+    CSM_REQUIRE(logits && targets && loss_rows && R > 0 && R < (1ll << 31) && V > 0 && ldl >= V, "csm_ce_fwd_bwd: bad arguments");
+    CSM_REQUIRE(!dlogits || ldd >= V, "csm_ce_fwd_bwd: ldd < V");
+    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, loss_rows, (bf16_t*)dlogits, V, ldl,
+                       ldd, grad_scale);
+    CSM_CHECK_LAUNCH("csm_ce_fwd_bwd");
+    return 0;
+}
+
+extern "C" int csm_reduce_sum_f32(const float* x, long long n, float scale, float* out, hipStream_t stream) {
+    CSM_REQUIRE(x && out && n > 0, "csm_reduce_sum_f32: bad arguments");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, stream, x, n, scale, out);
+    CSM_CHECK_LAUNCH("csm_reduce_sum_f32");
+    return 0;
+}
+
+#define CSM_SUMSQ_BLOCKS 1024
+extern "C" int csm_sumsq_blocks(void) { return CSM_SUMSQ_BLOCKS; }
+
+// partials must hold csm_sumsq_blocks() floats per call; several ranges can be reduced into consecutive slots.
+extern "C" int csm_sumsq_bf16(const void* g, long long n, float* partials, hipStream_t stream) {
+    CSM_REQUIRE(g && partials && n > 0 && ((uintptr_t)g & 15) == 0, "csm_sumsq_bf16: bad arguments");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(CSM_SUMSQ_BLOCKS), dim3(256), 0, stream, (const bf16_t*)g, n, partials);
+    CSM_CHECK_LAUNCH("csm_sumsq_bf16");
+    return 0;
+}
+
+extern "C" int csm_clip_coef(const float* partials, int n_partials, float max_norm, float* norm_and_coef,
+                             hipStream_t stream) {
+    CSM_REQUIRE(partials && norm_and_coef && n_partials > 0, "csm_clip_coef: bad arguments");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1024), 0, stream, partials, n_partials, max_norm, norm_and_coef);
+    CSM_CHECK_LAUNCH("csm_clip_coef");
+    return 0;
+}
+
+extern "C" int csm_adamw_step(float* master, float* m, float* v, void* param, const void* grad, long long n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step,
+                              const float* norm_and_coef, float grad_mul, hipStream_t stream) {
+    CSM_REQUIRE(master && m && v && param && grad && n > 0 && step > 0, "csm_adamw_step: bad arguments");
+    CSM_REQUIRE((n & 7) == 0, "csm_adamw_step: n must be a multiple of 8 (pad the arena)");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 3, 256, 4096)), dim3(256), 0, stream, master, m, v, (bf16_t*)param,
+                       (const bf16_t*)grad, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, norm_and_coef, grad_mul);
+    CSM_CHECK_LAUNCH("csm_adamw_step");
+    return 0;
+}
+
+extern "C" int csm_f32_to_bf16(const float* src, void* dst, long long n, int accumulate, hipStream_t stream) {
+    CSM_REQUIRE(src && dst && n > 0 && (n & 7) == 0, "csm_f32_to_bf16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n >> 3, 256, 4096)), dim3(256), 0, stream, src, (bf16_t*)dst, n,
+                       accumulate);
+    CSM_CHECK_LAUNCH("csm_f32_to_bf16");
+    return 0;
+}
+
+extern "C" int csm_add_f32_into_bf16(void* a, const float* b, long long n, hipStream_t stream) {
+    CSM_REQUIRE(a && b && n > 0 && (n & 7) == 0, "csm_add_f32_into_bf16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n >> 3, 256, 4096)), dim3(256), 0, stream, (bf16_t*)a, b, n);
+    CSM_CHECK_LAUNCH("csm_add_f32_into_bf16");
+    return 0;
+}

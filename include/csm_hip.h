@@ -1,0 +1,109 @@
+/* libcsm_hip.so - C ABI of the MI355X (gfx950) hot path for CSM training / generation.
+ *
+ * The reference (imaginateit/csm-train-pytorch) is pure Python and has no FFI: its boundary for this path is
+ * the Python API of csm.models.model / csm.training.utils / csm.training.trainer / csm.training.lora_trainer /
+ * csm.generator.  The host-side mirror of that API lives in csm-train-pytorch_amd/csm/ and calls ONLY the entry
+ * points below (through ctypes).  Each entry names the reference arithmetic it replaces (paths relative to the
+ * reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch-allocated); the library owns nothing;
+ *   - bf16 tensors are passed as void* (raw uint16 storage), row-major, 16-byte aligned;
+ *   - all work is enqueued on the caller's hipStream_t; nothing synchronises, allocates or frees (graph-capturable);
+ *   - return value 0 = ok, non-zero = error (1 bad argument, 2 launch failure, 3 no device, 4 wrong arch);
+ *     csm_last_error() returns the text for the calling thread.  No exception crosses the boundary.
+ */
+#ifndef CSM_HIP_H
+#define CSM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* csm_stream_t; /* == hipStream_t */
+
+int csm_abi_version(void);
+const char* csm_last_error(void);
+int csm_device_check(int device);
+
+/* ---- K3/K6/K7/K8/K9/K10/K11: every dense contraction -------------------------------------------------------
+ * C[M,N] = alpha * opA(A) . opB(B)^T (+ R), bf16 in, fp32 accumulate, bf16 or fp32 out, optional batch.
+ *   transA=0: A is [M][K] (lda)      transA=1: A is [K][M] (lda)
+ *   transB=0: B is [N][K] (ldb)      transB=1: B is [K][N] (ldb)
+ * Replaces torchtune nn.Linear q/k/v/output_proj, w1/w2/w3 (model.py:13-42), Model.projection, codebook0_head
+ * and torch.mm(decoder_h, audio_head[i-1]) (src/csm/models/model.py:124-126,172,184,187), their autograd
+ * backward products, and the LoRA A/B products of src/csm/mlx/components/lora.py:71-105.
+ * R (bf16, ldr) may alias C (accumulate).  lda/ldb multiples of 8; the contiguous dimension of A and of B a
+ * multiple of 8. */
+int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                  int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long strideA,
+                  long long strideB, long long strideC, long long strideR, csm_stream_t stream);
+
+/* ---- K2: torchtune RMSNorm (sa_norm / mlp_norm / norm; eps=1e-5 at model.py:22,39) -------------------------- */
+int csm_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int M, int D, float eps, csm_stream_t stream);
+int csm_rmsnorm_bwd_blocks(void);
+int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rstd, const void* dy, const void* dres, void* dx,
+                    float* dscale_partials /* [csm_rmsnorm_bwd_blocks()][D] or NULL */, int M, int D, csm_stream_t stream);
+int csm_colsum_bf16(const float* partials, int rows, int D, void* dst, int accumulate, csm_stream_t stream);
+
+/* ---- K4: torchtune Llama3ScaledRoPE (rope_base=500000, scale_factor=32: model.py:23-24,40-41), interleaved
+ * pairs, in place on the q and k heads of the fused qkv buffer; inverse=1 is the backward rotation.
+ * table = [P][head_dim/2][2] (cos,sin) fp32; pos = int32 [M] or NULL (position = row % S). */
+int csm_rope(void* qkv, const float* table, const int* pos, long long M, int S, int n_heads_qk, int head_dim, int ld,
+             int inverse, csm_stream_t stream);
+
+/* ---- K5: causal GQA attention replacing torchtune MultiHeadAttention -> F.scaled_dot_product_attention with the
+ * mask of model.py:59-76 / training/utils.py:90-91.  qkv [B*S][(H+2KV)*HD]; out [B*S][H*HD]; lse [B][H][S]. */
+int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, int HD, csm_stream_t stream);
+int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                 float* delta_ws /* [B][H][S] */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
+
+/* ---- K7: SwiGLU of torchtune FeedForward: out = silu(gate) * up with gu = [gate | up] ([M][2F]) ---------------- */
+int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, csm_stream_t stream);
+int csm_swiglu_bwd(const void* gu, const void* dout, void* dgu, long long M, int F, csm_stream_t stream);
+
+/* ---- K1: Model._embed_tokens + mask-mul-sum (model.py:202-217, training/utils.py:85-87) ---------------------- *
+ * tokens int64 [M][K+1] (K audio slots then the text slot), mask uint8 [M][K+1]; out bf16 [M][D].
+ * Backward scatter-adds into fp32 scratch tables (same shapes as the embeddings). */
+int csm_embed_fwd(const long long* tokens, const uint8_t* mask, const void* text_emb, const void* audio_emb, void* out,
+                  long long M, int K, int D, int audio_vocab, csm_stream_t stream);
+int csm_embed_bwd(const long long* tokens, const uint8_t* mask, const void* dh, float* d_text, float* d_audio,
+                  long long M, int K, int D, int audio_vocab, csm_stream_t stream);
+
+/* depth-decoder teacher forcing (model.py:175-189): out[n][0]=hidden[rows[n]], out[n][i]=audio_emb[code_{i-1}+(i-1)V] */
+int csm_decoder_input_fwd(const void* hidden, const int* rows, const long long* codes, const void* audio_emb, void* out,
+                          long long N, int K, int D, int audio_vocab, csm_stream_t stream);
+int csm_decoder_input_bwd(const void* dseq, const int* rows, const long long* codes, float* d_hidden, float* d_audio,
+                          long long N, int K, int D, int audio_vocab, csm_stream_t stream);
+
+/* ---- K9/K11: F.cross_entropy (training/utils.py:102-105) fused with its backward ------------------------------ *
+ * logits fp32 [R][ldl]; targets int64 [R] (<0 = row excluded); loss_rows fp32 [R]; dlogits bf16 [R][ldd] or NULL. */
+int csm_ce_fwd_bwd(const float* logits, const long long* targets, float* loss_rows, void* dlogits, long long R, int V,
+                   int ldl, int ldd, float grad_scale, csm_stream_t stream);
+int csm_reduce_sum_f32(const float* x, long long n, float scale, float* out, csm_stream_t stream);
+
+/* ---- K12/K13: clip_grad_norm_ + AdamW (training/trainer.py:166-173,271-277) ------------------------------------ */
+int csm_sumsq_blocks(void);
+int csm_sumsq_bf16(const void* g, long long n, float* partials /* [csm_sumsq_blocks()] */, csm_stream_t stream);
+int csm_clip_coef(const float* partials, int n_partials, float max_norm, float* norm_and_coef /* [2] */, csm_stream_t stream);
+int csm_adamw_step(float* master, float* m, float* v, void* param, const void* grad, long long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, const float* norm_and_coef /* or NULL */,
+                   float grad_mul, csm_stream_t stream);
+int csm_f32_to_bf16(const float* src, void* dst, long long n, int accumulate, csm_stream_t stream);
+int csm_add_f32_into_bf16(void* a, const float* b, long long n, csm_stream_t stream);
+
+/* ---- K14: sample_topk + _multinomial_sample_one_no_sync (model.py:79-96), Exp(1) noise q supplied ---------------- */
+int csm_sample_topk(const float* logits, const float* q, int* out, int rows, int V, int ldl, int topk, float temperature,
+                    csm_stream_t stream);
+
+/* ---- K16 (RVQ part): Mimi split residual VQ behind generator.py:117,209 ------------------------------------------ */
+int csm_rvq_encode(const float* x, const float* codebooks, long long* codes, int T, int K, int C, int D, int n_semantic,
+                   csm_stream_t stream);
+int csm_rvq_decode(const long long* codes, const float* codebooks, float* out, int T, int K, int C, int D,
+                   csm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSM_HIP_H */

@@ -334,7 +334,7 @@ def rvq_encode(x: torch.Tensor, codebooks: torch.Tensor, n_semantic: int = 1) ->
     """x [T,D] latent frames (already input-projected), codebooks [K,C,D] -> codes [K,T] int64.
 
     Semantic quantiser(s) see x; the acoustic chain starts again from x (split RVQ) and each layer
-    quantises the running residual.  Distance = squared L2 in fp32; argmin keeps the first minimum.
+    quantises the running residual (fp32).  Distance = squared L2; argmin keeps the first minimum.
     """
     K = codebooks.shape[0]
     codes = torch.empty(K, x.shape[0], dtype=torch.int64)
@@ -343,7 +343,8 @@ def rvq_encode(x: torch.Tensor, codebooks: torch.Tensor, n_semantic: int = 1) ->
         r = x.float().clone()
         for kk in range(lo, hi):
             cb = codebooks[kk].float()
-            d = (r * r).sum(-1, keepdim=True) - 2.0 * (r @ cb.t()) + (cb * cb).sum(-1)[None, :]
+            # distances in float64 so that the winner does not depend on a summation order
+            d = ((r.double()[:, None, :] - cb.double()[None, :, :]) ** 2).sum(-1)
             idx = torch.argmin(d, dim=-1)
             codes[kk] = idx
             r = r - cb[idx]

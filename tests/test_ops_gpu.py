@@ -1,0 +1,328 @@
+"""Per-kernel parity: HIP (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances: index / integer outputs bit-exact; bf16 kernels are compared with the oracle evaluated in fp32 on the
+SAME bf16-rounded inputs, so the only error left is fp32-accumulate ordering + one bf16 output rounding
+(relative 2^-8): tolerance = 2e-2 * output scale unless stated.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import csm_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+def close(name, got, ref, tol):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert math.isfinite(err) and err <= tol * scale, f"{name}: max abs err {err:.4g} vs scale {scale:.4g} (tol {tol})"
+    return err / scale
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 72), (1000, 2112, 1024), (64, 8, 256), (300, 128, 8)])
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm(dev, M, N, K, mode):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    if mode == "nt":      # C = A[M,K] B[N,K]^T
+        A, B = rnd((M, K), g), rnd((N, K), g)
+        ref = A.float() @ B.float().t()
+        tA, tB = False, False
+    elif mode == "nn":    # C = A[M,K] B[K,N]
+        if N % 8:
+            pytest.skip("N must be a multiple of 8 for [K][N] operands")
+        A, B = rnd((M, K), g), rnd((K, N), g)
+        ref = A.float() @ B.float()
+        tA, tB = False, True
+    else:                 # C = A[K,M]^T B[K,N]
+        if N % 8 or M % 8:
+            pytest.skip("M,N must be multiples of 8 for k-strided operands")
+        A, B = rnd((K, M), g), rnd((K, N), g)
+        ref = A.float().t() @ B.float()
+        tA, tB = True, True
+    R = rnd((M, N), g)
+    Ad, Bd, Rd = A.to(dev), B.to(dev), R.to(dev)
+    C = torch.empty(M, N, dtype=BF, device=dev)
+    ops.gemm(Ad, Bd, C, None, tA, tB)
+    close(f"gemm {mode}", C, ref, 1e-2)
+    C32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(Ad, Bd, C32, Rd, tA, tB, alpha=0.5)
+    close(f"gemm {mode} f32+R", C32, 0.5 * ref + R.float(), 2e-5 * math.sqrt(K))
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I with an asymmetric B catches a transposed C write (both operand orders)."""
+    from csm.hip import ops
+    n = 128
+    eye = torch.eye(n, dtype=BF)
+    B = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(BF)
+    C = torch.empty(n, n, dtype=torch.float32, device=dev)
+    ops.gemm(eye.to(dev), B.to(dev), C, None, False, False)
+    assert torch.equal(C.cpu(), B.float().t())
+    ops.gemm(eye.to(dev), B.to(dev), C, None, False, True)
+    assert torch.equal(C.cpu(), B.float())
+    ops.gemm(B.to(dev), eye.to(dev), C, None, True, True)
+    assert torch.equal(C.cpu(), B.float().t())
+
+
+def test_gemm_batched(dev):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(5)
+    nb, M, K, N = 3, 72, 128, 200
+    A = rnd((M, nb * K), g)             # batch b reads columns [b*K, (b+1)*K)
+    B = rnd((nb, K, N), g)
+    C = torch.empty(nb, M, N, dtype=torch.float32, device=dev)
+    Ad, Bd = A.to(dev), B.to(dev)
+    ops.gemm(Ad[:, :K], Bd[0], C[0], None, False, True, batch=nb, sA=K, sB=K * N, sC=M * N)
+    ref = torch.stack([A[:, b * K:(b + 1) * K].float() @ B[b].float() for b in range(nb)])
+    close("gemm batched", C, ref, 2e-5 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,D", [(37, 256), (64, 1024), (130, 2048)])
+def test_rmsnorm(dev, M, D):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(D + M)
+    x, w, dy, dres = rnd((M, D), g, 2.0), (1 + 0.1 * torch.randn(D, generator=g)).to(BF), rnd((M, D), g), rnd((M, D), g)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    y_ref = O.rmsnorm(xr, wr)
+    y_ref.backward(dy.float())
+    xd, wd = x.to(dev), w.to(dev)
+    y = torch.empty(M, D, dtype=BF, device=dev)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    ops.rmsnorm_fwd(xd, wd, y, rstd)
+    close("rmsnorm fwd", y, y_ref, 1e-2)
+    close("rstd", rstd, torch.rsqrt(x.float().pow(2).mean(-1) + 1e-5), 1e-5)
+    dx = torch.empty(M, D, dtype=BF, device=dev)
+    parts = torch.empty(ops.lib.csm_rmsnorm_bwd_blocks(), D, dtype=torch.float32, device=dev)
+    ops.rmsnorm_bwd(xd, wd, rstd, dy.to(dev), dx, dres.to(dev), parts)
+    close("rmsnorm dx", dx, xr.grad + dres.float(), 1e-2)
+    dw = torch.zeros(D, dtype=BF, device=dev)
+    ops.colsum_bf16(parts, dw)
+    close("rmsnorm dscale", dw, wr.grad, 1e-2)
+
+
+@pytest.mark.parametrize("hd,H,KV", [(64, 4, 2), (128, 2, 1)])
+def test_rope(dev, hd, H, KV):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(hd)
+    B, S = 2, 50
+    ld = (H + 2 * KV) * hd
+    qkv = rnd((B * S, ld), g)
+    table = O.rope_table(128, hd)
+    pos = torch.arange(S).unsqueeze(0).repeat(B, 1)
+    q = qkv[:, :H * hd].view(B, S, H, hd)
+    k = qkv[:, H * hd:(H + KV) * hd].view(B, S, KV, hd)
+    ref = qkv.clone().float()
+    ref[:, :H * hd] = O.rope(q.float(), table, pos).reshape(B * S, -1)
+    ref[:, H * hd:(H + KV) * hd] = O.rope(k.float(), table, pos).reshape(B * S, -1)
+    d = qkv.to(dev)
+    ops.rope(d, table.to(dev), S, H + KV, hd)
+    close("rope fwd", d, ref, 1e-2)
+    assert torch.equal(d[:, (H + KV) * hd:].cpu(), qkv[:, (H + KV) * hd:]), "v must be untouched"
+    # inverse rotation == autograd backward of the rotation
+    qf = q.float().requires_grad_(True)
+    up = rnd((B, S, H, hd), g).float()
+    O.rope(qf, table, pos).backward(up)
+    buf = torch.zeros(B * S, ld, dtype=BF)
+    buf[:, :H * hd] = up.reshape(B * S, -1).to(BF)
+    bd = buf.to(dev)
+    ops.rope(bd, table.to(dev), S, H + KV, hd, inverse=True)
+    close("rope bwd", bd[:, :H * hd], qf.grad.reshape(B * S, -1), 1e-2)
+    # explicit positions
+    p2 = torch.randint(0, 128, (B * S,), generator=g, dtype=torch.int32)
+    d2 = qkv.to(dev)
+    ops.rope(d2, table.to(dev), S, H + KV, hd, pos=p2.to(dev))
+    ref2 = O.rope(q.float(), table, p2.long().view(B, S)).reshape(B * S, -1)
+    close("rope pos", d2[:, :H * hd], ref2, 1e-2)
+
+
+def test_swiglu(dev):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(1)
+    M, F = 70, 512
+    gu, dout = rnd((M, 2 * F), g, 2.0), rnd((M, F), g)
+    gr = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(gr[:, :F]) * gr[:, F:]
+    ref.backward(dout.float())
+    out = torch.empty(M, F, dtype=BF, device=dev)
+    ops.swiglu_fwd(gu.to(dev), out)
+    close("swiglu fwd", out, ref, 1e-2)
+    dgu = torch.empty(M, 2 * F, dtype=BF, device=dev)
+    ops.swiglu_bwd(gu.to(dev), dout.to(dev), dgu)
+    close("swiglu bwd", dgu, gr.grad, 1e-2)
+
+
+def _attn_ref(qkv, B, S, H, KV, hd):
+    q = qkv[:, :H * hd].view(B, S, H, hd)
+    k = qkv[:, H * hd:(H + KV) * hd].view(B, S, KV, hd)
+    v = qkv[:, (H + KV) * hd:].view(B, S, KV, hd)
+    return O.attention(q, k, v).reshape(B * S, H * hd)
+
+
+@pytest.mark.parametrize("B,S,H,KV,hd", [(1, 64, 1, 1, 64), (2, 200, 4, 2, 64), (1, 512, 8, 2, 64), (3, 32, 2, 1, 128),
+                                        (2, 100, 4, 2, 128)])
+def test_attention(dev, B, S, H, KV, hd):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(S + hd)
+    qkv = rnd((B * S, (H + 2 * KV) * hd), g)
+    dout = rnd((B * S, H * hd), g)
+    qr = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qr, B, S, H, KV, hd)
+    ref.backward(dout.float())
+    qd = qkv.to(dev)
+    out = torch.empty(B * S, H * hd, dtype=BF, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd(qd, out, lse, B, S, H, KV, hd)
+    close("attn fwd", out, ref, 1.5e-2)
+    # lse check
+    q = qkv[:, :H * hd].view(B, S, H, hd).float().transpose(1, 2)
+    k = qkv[:, H * hd:(H + KV) * hd].view(B, S, KV, hd).float().repeat_interleave(H // KV, 2).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    s = s.masked_fill(~torch.tril(torch.ones(S, S, dtype=torch.bool)), float("-inf"))
+    close("attn lse", lse, torch.logsumexp(s, -1), 1e-3)
+    dqkv = torch.zeros_like(qd)
+    delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_bwd(qd, out, dout.to(dev), lse, dqkv, delta, B, S, H, KV, hd)
+    gq = qr.grad
+    close("attn dq", dqkv[:, :H * hd], gq[:, :H * hd], 2e-2)
+    close("attn dk", dqkv[:, H * hd:(H + KV) * hd], gq[:, H * hd:(H + KV) * hd], 2e-2)
+    close("attn dv", dqkv[:, (H + KV) * hd:], gq[:, (H + KV) * hd:], 2e-2)
+
+
+def test_attention_spike(dev):
+    """One key dominates one query row late in the sequence: forces the online-softmax rescale path."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(3)
+    B, S, H, KV, hd = 1, 256, 1, 1, 64
+    qkv = rnd((S, 3 * hd), g, 0.5)
+    qkv[200, :hd] = 4.0
+    qkv[150, hd:2 * hd] = 4.0
+    ref = _attn_ref(qkv.float(), B, S, H, KV, hd)
+    out = torch.empty(S, hd, dtype=BF, device=dev)
+    lse = torch.empty(1, 1, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd(qkv.to(dev), out, lse, B, S, H, KV, hd)
+    close("attn spike", out, ref, 1.5e-2)
+
+
+def test_embed(dev):
+    from csm.hip import ops
+    cfg = O.tiny_cfg()
+    params = {k: v.to(BF) for k, v in O.init_params(cfg, seed=2).items()}
+    tokens, mask, _ = O.synthetic_batch(cfg, 2, 40, seed=4)
+    mask[0, 3, :] = True   # a row with every slot live
+    ref = O.embed_masked_sum({k: v.float() for k, v in params.items()}, cfg, tokens, mask)
+    M = tokens.shape[0] * tokens.shape[1]
+    out = torch.empty(M, cfg.backbone.dim, dtype=BF, device=dev)
+    te, ae = params["text_embeddings.weight"].to(dev), params["audio_embeddings.weight"].to(dev)
+    tk, mk = tokens.view(M, -1).to(dev), mask.view(M, -1).to(torch.uint8).to(dev)
+    ops.embed_fwd(tk, mk, te, ae, out, cfg.audio_vocab)
+    close("embed fwd", out, ref.view(M, -1), 1e-2)
+    dh = rnd((M, cfg.backbone.dim), torch.Generator().manual_seed(9))
+    pt = {k: params[k].float().requires_grad_(True) for k in ("text_embeddings.weight", "audio_embeddings.weight")}
+    O.embed_masked_sum(pt, cfg, tokens, mask).view(M, -1).backward(dh.float())
+    dt = torch.zeros_like(te, dtype=torch.float32)
+    da = torch.zeros_like(ae, dtype=torch.float32)
+    ops.embed_bwd(tk, mk, dh.to(dev), dt, da, cfg.audio_vocab)
+    close("embed d_text", dt, pt["text_embeddings.weight"].grad, 1e-5)
+    close("embed d_audio", da, pt["audio_embeddings.weight"].grad, 1e-5)
+
+
+def test_ce(dev):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(6)
+    R, V, ld = 77, 2051, 2112
+    logits = torch.zeros(R, ld)
+    logits[:, :V] = torch.randn(R, V, generator=g) * 3
+    tgt = torch.randint(0, V, (R,), generator=g)
+    tgt[5] = -1
+    lr = logits[:, :V].clone().requires_grad_(True)
+    valid = tgt >= 0
+    loss_ref = torch.nn.functional.cross_entropy(lr[valid], tgt[valid], reduction="sum")
+    loss_ref.backward()
+    ld_ = logits.to(dev)
+    rows = torch.empty(R, dtype=torch.float32, device=dev)
+    dl = torch.full((R, ld), 7.0, dtype=BF, device=dev)
+    ops.ce_fwd_bwd(ld_, tgt.to(dev), rows, dl, V, 0.25)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    ops.reduce_sum(rows, out)
+    assert abs(out.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    gref = torch.zeros(R, V)
+    gref[valid] = lr.grad[valid] * 0.25
+    close("ce dlogits", dl[:, :V], gref, 1e-2)
+    assert (dl[:, V:] == 0).all() and (dl[5] == 0).all()
+
+
+def test_optimizer(dev):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(8)
+    n = 8 * 1000
+    p0 = torch.randn(n, generator=g)
+    master = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    pbf = master.to(BF)
+    po, mo, vo = p0.clone(), torch.zeros(n), torch.zeros(n)
+    nb = ops.sumsq_blocks()
+    for step in range(1, 4):
+        grad = rnd((n,), g, 0.3)
+        parts = torch.empty(nb, dtype=torch.float32, device=dev)
+        ops.sumsq_bf16(grad.to(dev), parts)
+        nc = torch.empty(2, dtype=torch.float32, device=dev)
+        ops.clip_coef(parts, 1.0, nc)
+        gl = [grad.float().clone()]
+        norm, coef = O.clip_grad_norm(gl, 1.0)
+        assert abs(nc[0].item() - norm.item()) <= 1e-4 * norm.item()
+        assert abs(nc[1].item() - coef) <= 1e-4 * coef
+        ops.adamw_step(master, m, v, pbf, grad.to(dev), 1e-2, 0.9, 0.999, 1e-8, 0.01, step, nc)
+        O.adamw_step(po, gl[0], mo, vo, step, 1e-2)
+    close("adamw master", master, po, 1e-5)
+    close("adamw m", m, mo, 1e-4)
+    close("adamw v", v, vo, 1e-4)
+    assert torch.equal(pbf.cpu(), master.cpu().to(BF))
+
+
+def test_sampler_golden(dev):
+    import numpy as np, os
+    from csm.hip import ops
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_small.npz"))
+    logits, q, want = (torch.from_numpy(z[k]) for k in ("sampler_logits", "sampler_q", "sampler_out"))
+    out = torch.empty(logits.shape[0], dtype=torch.int32, device=dev)
+    ops.sample_topk(logits.to(dev), q.to(dev), out, 50, 0.9)
+    assert torch.equal(out.cpu(), want.view(-1)), (out.cpu(), want.view(-1))
+    # live oracle comparison on fresh draws, padded row stride
+    g = torch.Generator().manual_seed(31)
+    lg = torch.randn(64, 2051, generator=g) * 2
+    qq = torch.empty(64, 2051).exponential_(1, generator=g)
+    pad = torch.zeros(64, 2112)
+    pad[:, :2051] = lg
+    out = torch.empty(64, dtype=torch.int32, device=dev)
+    ops.sample_topk(pad.to(dev), qq.to(dev), out, 50, 0.9, V=2051)
+    assert torch.equal(out.cpu(), O.sample_topk(lg, 50, 0.9, qq).view(-1))
+
+
+def test_rvq(dev):
+    import numpy as np, os
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(21)   # same draws as tests/golden/make_golden.py
+    cbs = torch.randn(8, 2048, 256, generator=g)
+    x = torch.randn(40, 256, generator=g) * 4
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_small.npz"))
+    codes = torch.empty(8, 40, dtype=torch.int64, device=dev)
+    ops.rvq_encode(x.to(dev), cbs.to(dev), codes, 1)
+    assert torch.equal(codes.cpu(), torch.from_numpy(z["rvq_codes"])), "RVQ indices must be bit-exact"
+    out = torch.empty(40, 256, dtype=torch.float32, device=dev)
+    ops.rvq_decode(codes, cbs.to(dev), out)
+    assert torch.equal(out.cpu(), O.rvq_decode(codes.cpu(), cbs)), "RVQ decode is an ordered fp32 sum: exact"
+    # encode -> decode -> encode is a fixed point for the first (semantic) quantiser
+    codes2 = torch.empty(1, 40, dtype=torch.int64, device=dev)
+    ops.rvq_encode(cbs[0][codes[0].cpu()].to(dev).contiguous(), cbs[:1].to(dev).contiguous(), codes2, 1)
+    assert torch.equal(codes2[0], codes[0])
