@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train tokens/sec (text+audio positions) of CSM-1B, bf16, seq 2048, on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full optimiser step of ``CSMTrainer.train_step`` on one fixed synthetic interleaved text+audio batch
+(BASELINE.json configs[1]: full-param bf16, S=2048, B=4 per GPU): embedding -> 16-layer backbone -> codebook-0 CE
+(+ teacher-forced depth decoder on 1/16 of the frames, "mode C" of SURVEY 8d) -> backward -> bf16 gradient all-reduce
+(N>1) -> global-norm clip -> fused AdamW.  tokens/s = N * B * S / step time (metric definition of the reference's own
+harness, src/csm/training/run_lora_benchmark.py:357-361).  Inputs and weights are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="sequences per GPU")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--mode", choices=["A", "B", "C"], default="C",
+                    help="A: semantic CE only (reference loss); B: + decoder on all frames; C: + decoder on 1/16 of frames")
+    ap.add_argument("--lora", action="store_true", help="configs[2]: LoRA r=8 q_proj/v_proj instead of full-param")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seq", type=int, default=256, help="positions of the bounded CPU-baseline sample")
+    ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only; the number is not the metric)")
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP-event timing of every GEMM launch of ONE step inside the timed region (events are recorded on the stream
+    the kernels run on: torch's current stream).  Gives per-variant algorithmic FLOP / measured time."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        from csm.hip import ops
+        self.ops, self.orig = ops, ops.gemm
+        timer = self
+
+        def timed(A, B, C, R=None, transA=False, transB=False, alpha=1.0, batch=1, sA=0, sB=0, sC=0, sR=0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer.orig(A, B, C, R, transA, transB, alpha, batch, sA, sB, sC, sR)
+            e1.record()
+            M, N = C.shape
+            K = A.shape[0] if transA else A.shape[1]
+            kind = {(False, False): "nt_fwd", (False, True): "nn_dgrad", (True, True): "tn_wgrad", (True, False): "tt"}[(transA, transB)]
+            kind += "_f32" if C.dtype == torch.float32 else "_bf16"
+            timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1))
+            return out
+
+        ops.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flop, e0, e1 in self.records:
+            d = agg.setdefault(kind, [0.0, 0.0, 0])
+            d[0] += flop
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        return {k: {"tflops": v[0] / v[1] / 1e12, "time_ms": v[1] * 1e3, "launches": v[2], "avg_us": v[1] / v[2] * 1e6,
+                    "flop": v[0]} for k, v in agg.items() if v[1] > 0}
+
+
+def cpu_baseline(model, cfg_fn, seq, seed, sw, aw):
+    """The oracle (CPU restatement of the reference PyTorch path) on this box's host cores: one full-param fp32 train
+    step (loss -> backward -> clip -> AdamW), semantic loss only (what the reference computes), B=1, S=seq.
+    Uses the SAME weights as the GPU model (its bf16 values widened to fp32), so the two losses are comparable."""
+    from oracle import csm_oracle as O
+    cfg = cfg_fn()
+    params = {k: v.float().cpu().requires_grad_(True) for k, v in model._views(model.arena).items()}
+    tokens, mask, targets = O.synthetic_batch(cfg, 1, seq, seed=seed)
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    total, det = O.compute_loss(params, cfg, tokens, mask, targets, sw, aw, acoustic_rows="off")
+    total.backward()
+    plist = list(params.values())
+    opt = torch.optim.AdamW(plist, lr=1e-5, weight_decay=0.01)
+    torch.nn.utils.clip_grad_norm_(plist, 1.0)
+    opt.step()
+    dt = time.time() - t0
+    return dict(value=seq / dt, unit="tokens/s", cores=threads, kind="port",
+                sample=f"1 full-param fp32 train step (oracle: fwd+bwd+clip+AdamW, semantic loss) at B=1,S={seq}, {dt:.1f}s",
+                loss=float(total)), (tokens, mask, targets)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from csm.data import SyntheticCSMDataset, collate_variable_length
+    from csm.models.model import Model, ModelArgs
+    from csm.training.trainer import CSMTrainer, csm_1b_args
+    from csm.training.lora import apply_lora_to_model
+    from csm.training.optim import FusedAdamW
+    from csm.training.dp import GradSync
+    from csm.training.utils import compute_loss
+
+    if a.tiny:
+        args = ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", 300, 67, 4)
+        a.seq = min(a.seq, 128)
+    else:
+        args = csm_1b_args()
+    model = Model(args, device=f"cuda:{local}", seed=0)          # random init, same on every rank
+    model.acoustic_mode = {"A": "off", "B": "all", "C": "amortized"}[a.mode]
+    tr = CSMTrainer("", os.path.join(ROOT, "gpurun_out", f"bench_rank{rank}"), device=f"cuda:{local}")
+    tr.logger.setLevel(30)
+    tr.model = model
+    if a.lora:
+        apply_lora_to_model(model, r=8, alpha=16.0, target_modules=["q_proj", "v_proj"])
+        tr.optimizer = FusedAdamW(model, {}, lora_lr=1e-4)
+        tr.grad_sync = GradSync.for_model(model) if GradSync.active() else None
+    else:
+        tr.prepare_optimizer()
+
+    ds = SyntheticCSMDataset(a.batch, a.seq, args.text_vocab_size, args.audio_vocab_size, args.audio_num_codebooks,
+                             seed=1234 + rank)
+    batch = {k: v.cuda() for k, v in collate_variable_length([ds[i] for i in range(a.batch)]).items()}
+
+    def step():
+        return tr.train_step(batch, 1, True, 1.0)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gt = None
+    for i in range(a.steps):
+        if i == a.steps - 1:
+            with GemmTimer() as gt:
+                loss, det = step()
+        else:
+            loss, det = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    ms = dt / a.steps * 1e3
+    tokens_per_s = world * a.batch * a.seq / (dt / a.steps)
+
+    if rank == 0:
+        kinds = gt.summary() if gt is not None else {}
+        bf = {k: v for k, v in kinds.items() if k.endswith("_bf16")}
+        dom = max(bf.items(), key=lambda kv: kv[1]["time_ms"]) if bf else (None, None)
+        roof = None
+        if dom[0] is not None:
+            roof = {"bound": "mfma", "kernel": f"gemm_kernel<{dom[0]}>", "achieved": round(dom[1]["tflops"], 2),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": None, "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
+                    "all_gemm_variants": {k: {"tflops": round(v["tflops"], 1), "ms_per_step": round(v["time_ms"], 2),
+                                              "launches": v["launches"]} for k, v in kinds.items()}}
+        out = {
+            "metric": "train tokens/sec (text+audio) CSM-1B bf16 seq2048", "value": round(tokens_per_s, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("tiny-plumbing" if a.tiny else "CSM-1B") + (" LoRA r=8 q_proj/v_proj" if a.lora else " full-param")
+                       + f" bf16 train step, seq={a.seq}, batch={a.batch}/GPU, loss mode {a.mode}"
+                       + (" (semantic CE + depth decoder on 1/16 of frames)" if a.mode == "C" else ""),
+                       "global_batch": world * a.batch, "seq_len": a.seq, "parallelism": f"dp{world}"},
+            "loss": float(loss), "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            from oracle import csm_oracle as O
+            cb, (ct, cm, cg) = cpu_baseline(model, (O.tiny_cfg if a.tiny else O.csm_1b_cfg), min(a.cpu_seq, a.seq), 4321, 100.0, 1.0)
+            mode = model.acoustic_mode
+            model.acoustic_mode = "off"
+            with torch.no_grad():
+                gl, _ = compute_loss(model, ct, cm, cg, 100.0, 1.0)
+            model.acoustic_mode = mode
+            cpu_loss = cb.pop("loss")
+            out["cpu_baseline"] = cb
+            out["parity_check"] = {"what": "loss of the same weights/batch: HIP bf16 path vs CPU fp32 oracle", "cpu_loss": cpu_loss,
+                                   "gpu_loss": float(gl), "rel_diff": abs(float(gl) - cpu_loss) / abs(cpu_loss)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,395 @@
+"""Explicit forward / backward schedule of the CSM train step over libcsm_hip.so.
+
+There is no autograd tape underneath: the layer structure is fixed, so the engine walks it forwards saving the
+activations the backward needs, then backwards issuing dgrad / wgrad GEMMs and the fused element-wise backward
+kernels, accumulating straight into the bf16 gradient arena (wgrad GEMM epilogue ``C += alpha * dY^T X``).
+It restates what autograd does for the reference hot loop ``compute_loss -> loss.backward()``
+(reference src/csm/training/utils.py:56-119, src/csm/training/trainer.py:245-263).
+
+Activations kept per layer (bf16 unless noted): x (block input), xn, qkv (post-RoPE), attn out, lse (fp32),
+h (post-attention residual), hn, gate|up, swiglu out, rstd x2 (fp32)  ~= 76 KB per position per backbone layer.
+With 288 GB of HBM nothing is recomputed.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .hip import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class _Stack:
+    """One Llama stack (backbone or decoder) bound to a model's arenas."""
+
+    def __init__(self, model, prefix: str):
+        self.m, self.prefix = model, prefix
+        self.c = model.bb if prefix == "backbone" else model.dc
+        self.acts: List[Dict[str, torch.Tensor]] = []
+
+    def w(self, name, grad=False):
+        return self.m.block(f"{self.prefix}.{name}", grad)
+
+    def _lora(self, layer: int, module: str):
+        lo = self.m.lora
+        return lo.get(self.prefix, layer, module) if lo is not None else None
+
+    # -------------------------------------------------------------------------------------------- forward
+    def forward(self, x: torch.Tensor, B: int, S: int, save: bool, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+        c, dev = self.c, x.device
+        M, d = x.shape
+        H, KV, hd, F = c.num_heads, c.num_kv_heads, c.head_dim, c.intermediate_dim
+        table = self.m.rope_table(self.prefix)
+        self.acts = []
+        for i in range(c.num_layers):
+            a: Dict[str, torch.Tensor] = {}
+            xn = torch.empty(M, d, dtype=BF16, device=dev)
+            rstd1 = torch.empty(M, dtype=F32, device=dev)
+            ops.rmsnorm_fwd(x, self.w(f"layers.{i}.sa_norm.scale"), xn, rstd1, c.norm_eps)
+            qkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
+            ops.linear_fwd(xn, self.w(f"layers.{i}.attn.qkv"), qkv)
+            hq, hk = H * hd, KV * hd
+            for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
+                ad = self._lora(i, mod)
+                if ad is not None:
+                    a[f"t_{mod}"] = ad.forward(xn, qkv[:, lo_:hi_])
+            ops.rope(qkv, table, S, H + KV, hd, pos=pos)
+            o = torch.empty(M, H * hd, dtype=BF16, device=dev)
+            lse = torch.empty(B, H, S, dtype=F32, device=dev)
+            ops.attn_fwd(qkv, o, lse, B, S, H, KV, hd)
+            h = torch.empty(M, d, dtype=BF16, device=dev)
+            ops.linear_fwd(o, self.w(f"layers.{i}.attn.output_proj.weight"), h, residual=x)
+            ad = self._lora(i, "output_proj")
+            if ad is not None:
+                a["t_output_proj"] = ad.forward(o, h)
+            hn = torch.empty(M, d, dtype=BF16, device=dev)
+            rstd2 = torch.empty(M, dtype=F32, device=dev)
+            ops.rmsnorm_fwd(h, self.w(f"layers.{i}.mlp_norm.scale"), hn, rstd2, c.norm_eps)
+            gu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
+            ops.linear_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu)
+            for mod, lo_, hi_ in (("w1", 0, F), ("w3", F, 2 * F)):
+                ad = self._lora(i, mod)
+                if ad is not None:
+                    a[f"t_{mod}"] = ad.forward(hn, gu[:, lo_:hi_])
+            act = torch.empty(M, F, dtype=BF16, device=dev)
+            ops.swiglu_fwd(gu, act)
+            out = torch.empty(M, d, dtype=BF16, device=dev)
+            ops.linear_fwd(act, self.w(f"layers.{i}.mlp.w2.weight"), out, residual=h)
+            ad = self._lora(i, "w2")
+            if ad is not None:
+                a["t_w2"] = ad.forward(act, out)
+            if save:
+                a.update(x=x, xn=xn, rstd1=rstd1, qkv=qkv, o=o, lse=lse, h=h, hn=hn, rstd2=rstd2, gu=gu, act=act)
+                self.acts.append(a)
+            x = out
+        xf = torch.empty(M, d, dtype=BF16, device=dev)
+        rstdf = torch.empty(M, dtype=F32, device=dev)
+        ops.rmsnorm_fwd(x, self.w("norm.scale"), xf, rstdf, c.norm_eps)
+        if save:
+            self.final = dict(x=x, rstd=rstdf)
+        return xf
+
+    # -------------------------------------------------------------------------------------------- backward
+    def backward(self, dxf: torch.Tensor, B: int, S: int, train_base: bool, alpha: float,
+                 pos: Optional[torch.Tensor] = None, on_layer_done=None) -> torch.Tensor:
+        """dxf = gradient w.r.t. the final-norm output.  Returns the gradient w.r.t. the stack input.
+        Weight gradients are accumulated into the gradient arena (scaled by ``alpha``... the incoming gradient is
+        already scaled, so alpha stays 1 unless a caller rescales)."""
+        c, dev = self.c, dxf.device
+        M, d = dxf.shape
+        H, KV, hd, F = c.num_heads, c.num_kv_heads, c.head_dim, c.intermediate_dim
+        table = self.m.rope_table(self.prefix)
+        nb = ops.lib.csm_rmsnorm_bwd_blocks()
+        parts = torch.empty(nb, d, dtype=F32, device=dev) if train_base else None
+        delta = torch.empty(B, H, S, dtype=F32, device=dev)
+
+        def norm_bwd(x, name, rstd, dy, dres):
+            dx = torch.empty(M, d, dtype=BF16, device=dev)
+            ops.rmsnorm_bwd(x, self.w(name), rstd, dy, dx, dres, parts)
+            if train_base:
+                ops.colsum_bf16(parts, self.w(name, grad=True), accumulate=True)
+            return dx
+
+        dx = norm_bwd(self.final["x"], "norm.scale", self.final["rstd"], dxf, None)
+        for i in reversed(range(c.num_layers)):
+            a = self.acts[i]
+            hq, hk = H * hd, KV * hd
+            # ---- MLP: out = h + w2(act)
+            dact = torch.empty(M, F, dtype=BF16, device=dev)
+            ops.linear_dx(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact)
+            ad = self._lora(i, "w2")
+            if ad is not None:
+                ad.backward(a["act"], dx, a["t_w2"], dact)
+            if train_base:
+                ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=True, alpha=alpha)
+            dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
+            ops.swiglu_bwd(a["gu"], dact, dgu)
+            del dact
+            dhn = torch.empty(M, d, dtype=BF16, device=dev)
+            ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
+            for mod, lo_, hi_ in (("w1", 0, F), ("w3", F, 2 * F)):
+                ad = self._lora(i, mod)
+                if ad is not None:
+                    ad.backward(a["hn"], dgu[:, lo_:hi_], a[f"t_{mod}"], dhn)
+            if train_base:
+                ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=True, alpha=alpha)
+            del dgu
+            dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx)   # + residual path
+            # ---- attention: h = x + output_proj(o)
+            do = torch.empty(M, H * hd, dtype=BF16, device=dev)
+            ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
+            ad = self._lora(i, "output_proj")
+            if ad is not None:
+                ad.backward(a["o"], dh, a["t_output_proj"], do)
+            if train_base:
+                ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=True, alpha=alpha)
+            dqkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
+            ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd)
+            ops.rope(dqkv, table, S, H + KV, hd, pos=pos, inverse=True)
+            dxn = torch.empty(M, d, dtype=BF16, device=dev)
+            ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
+            for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
+                ad = self._lora(i, mod)
+                if ad is not None:
+                    ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
+            if train_base:
+                ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=True, alpha=alpha)
+            dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh)
+            self.acts[i] = None
+            if on_layer_done is not None:
+                on_layer_done(self.prefix, i)
+        self.acts = []
+        return dx
+
+
+class Engine:
+    def __init__(self, model):
+        self.m = model
+        self.backbone = _Stack(model, "backbone")
+        self.decoder = _Stack(model, "decoder")
+        self.saved = None
+        self.grad_hook = None   # called as hook(prefix, layer) when a layer's weight gradients are final (DP overlap)
+
+    # -------------------------------------------------------------------------------------------- loss forward
+    def forward_loss(self, tokens: torch.Tensor, masks: torch.Tensor, targets: torch.Tensor, semantic_weight: float,
+                     acoustic_weight: float, save: bool, acoustic_rows: Optional[torch.Tensor] = None):
+        """Forward of ``compute_loss``.  Returns (total, semantic, acoustic) as 0-d fp32 GPU tensors."""
+        m, a = self.m, self.m.args
+        dev = m.device
+        B, S, K1 = tokens.shape
+        K, V, Vp = a.audio_num_codebooks, a.audio_vocab_size, m.vocab_pad
+        assert K1 == K + 1, f"tokens last dim must be {K + 1}"
+        if targets.shape[1] < S - 1:
+            raise ValueError(f"target_audio_tokens has {targets.shape[1]} frames, needs at least seq_len-1 = {S - 1}")
+        if S > m.bb.max_seq_len:
+            raise ValueError(f"sequence length {S} exceeds max_seq_len {m.bb.max_seq_len}")
+        M, d = B * S, m.bb.embed_dim
+        tk = tokens.reshape(M, K1).to(device=dev, dtype=torch.int64).contiguous()
+        mk = masks.reshape(M, K1).to(device=dev, dtype=torch.uint8).contiguous()
+        tg = targets.to(device=dev, dtype=torch.int64)
+        if int(tg.max()) >= V or int(tg.min()) < 0:
+            raise ValueError("target_audio_tokens out of range for audio_vocab_size")
+
+        h0 = torch.empty(M, d, dtype=BF16, device=dev)
+        ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, V)
+        hidden = self.backbone.forward(h0, B, S, save)
+
+        # codebook-0 head + CE over positions [0, S-1) of every sequence (reference utils.py:96-106)
+        logits = torch.empty(M, Vp, dtype=F32, device=dev)
+        ops.linear_fwd(hidden, m.block("codebook0_head.padded"), logits)
+        t0 = torch.full((B, S), -1, dtype=torch.int64, device=dev)
+        t0[:, :S - 1] = tg[:, :S - 1, 0]
+        t0 = t0.reshape(M).contiguous()
+        n_sem = B * (S - 1)
+        rows_loss = torch.empty(M, dtype=F32, device=dev)
+        ops.ce_fwd_bwd(logits, t0, rows_loss, None, V, 0.0)
+        sem = torch.empty(1, dtype=F32, device=dev)
+        ops.reduce_sum(rows_loss, sem, 1.0 / n_sem)
+
+        ac = torch.zeros(1, dtype=F32, device=dev)
+        dec = None
+        if m.acoustic_mode != "off":
+            rows = self._acoustic_rows(B, S, acoustic_rows)
+            dec = self._decoder_forward(hidden, rows, tg, B, S, save)
+            ops.reduce_sum(dec["rows_loss"], ac, 1.0 / dec["n_rows"])
+        total = semantic_weight * sem + acoustic_weight * ac
+        if save:
+            self.saved = dict(B=B, S=S, tk=tk, mk=mk, hidden=hidden, logits=logits, t0=t0, n_sem=n_sem, dec=dec,
+                              sw=float(semantic_weight), aw=float(acoustic_weight))
+        return total[0], sem[0], ac[0]
+
+    def _acoustic_rows(self, B, S, rows):
+        """Flattened (b*S + p) indices, p < S-1, of the positions whose frame trains the depth decoder."""
+        dev = self.m.device
+        if rows is not None:
+            r = rows.to(device=dev, dtype=torch.int64)            # given over the B*(S-1) row space of compute_loss
+            b, p = r // (S - 1), r % (S - 1)
+            return (b * S + p).to(torch.int32).contiguous()
+        allr = (torch.arange(B, device=dev)[:, None] * S + torch.arange(S - 1, device=dev)[None, :]).reshape(-1)
+        if self.m.acoustic_mode == "all":
+            return allr.to(torch.int32).contiguous()
+        n = max(1, int(round(allr.numel() * self.m.acoustic_fraction)))
+        perm = torch.randperm(allr.numel(), device=dev)[:n].sort().values
+        return allr[perm].to(torch.int32).contiguous()
+
+    def _decoder_forward(self, hidden, rows, tg, B, S, save):
+        m, a = self.m, self.m.args
+        dev = m.device
+        K, V, Vp = a.audio_num_codebooks, a.audio_vocab_size, m.vocab_pad
+        N = rows.numel()
+        d, dd = m.bb.embed_dim, m.dc.embed_dim
+        codes = tg[:, :S, :].reshape(-1, K) if tg.shape[1] >= S else None
+        if codes is None:   # targets may be exactly S-1 long: index through (b, p)
+            b, p = rows.long() // S, rows.long() % S
+            codes = tg[b, p]
+        else:
+            codes = codes[rows.long()]
+        codes = codes.contiguous()
+        seq = torch.empty(N * K, d, dtype=BF16, device=dev)
+        ops.decoder_input_fwd(hidden, rows, codes, m.block("audio_embeddings.weight"), seq, V)
+        x0 = torch.empty(N * K, dd, dtype=BF16, device=dev)
+        ops.linear_fwd(seq, m.block("projection.weight"), x0)
+        xf = self.decoder.forward(x0, N, K, save)                                   # [N*K, dd]
+        logits = torch.empty(K - 1, N, Vp, dtype=F32, device=dev)
+        ah = m.block("audio_head.padded")                                           # [K-1, dd, Vp]
+        xf2 = xf.view(N, K * dd)
+        ops.gemm(xf2[:, dd:2 * dd], ah[0], logits[0], None, False, True, batch=K - 1, sA=dd, sB=dd * Vp, sC=N * Vp)
+        tgt = codes[:, 1:].t().contiguous().reshape(-1)                             # [(K-1)*N]
+        rows_loss = torch.empty((K - 1) * N, dtype=F32, device=dev)
+        ops.ce_fwd_bwd(logits.view(-1, Vp), tgt, rows_loss, None, V, 0.0)
+        out = dict(rows_loss=rows_loss, n_rows=(K - 1) * N)
+        if save:
+            out.update(rows=rows, codes=codes, seq=seq, xf=xf, logits=logits, tgt=tgt, N=N)
+        return out
+
+    # -------------------------------------------------------------------------------------------- backward
+    def backward(self, gscale: float = 1.0):
+        """Gradients of ``gscale * total`` accumulated into the gradient arena (and LoRA gradient tensors).
+        Which groups receive weight gradients follows ``model.trainable`` (freeze flags / LoRA)."""
+        if self.saved is None:
+            raise RuntimeError("backward() without a saved forward (was the forward run under no_grad?)")
+        s, m, a = self.saved, self.m, self.m.args
+        self.saved = None
+        dev = m.device
+        B, S = s["B"], s["S"]
+        K, V, Vp = a.audio_num_codebooks, a.audio_vocab_size, m.vocab_pad
+        M, d, dd = B * S, m.bb.embed_dim, m.dc.embed_dim
+        tr = m.trainable
+        train_embeddings, train_other = tr["embeddings"], tr["other"]
+        m.ensure_grads()
+        hidden = s["hidden"]
+        dhid_f32 = None
+        d_text = d_audio = None
+        if train_embeddings:
+            d_text = torch.zeros(m.block("text_embeddings.weight").shape, dtype=F32, device=dev)
+            d_audio = torch.zeros(m.block("audio_embeddings.weight").shape, dtype=F32, device=dev)
+
+        # ---- depth decoder (acoustic term)
+        dec = s["dec"]
+        if dec is not None and s["aw"] != 0.0:
+            N = dec["N"]
+            dl = torch.empty(K - 1, N, Vp, dtype=BF16, device=dev)
+            ops.ce_fwd_bwd(dec["logits"].view(-1, Vp), dec["tgt"], dec["rows_loss"], dl.view(-1, Vp), V,
+                           gscale * s["aw"] / dec["n_rows"])
+            ah = m.block("audio_head.padded")
+            dxf = torch.zeros(N, K * dd, dtype=BF16, device=dev)                   # position 0 has no head: stays 0
+            ops.gemm(dl[0], ah[0], dxf[:, dd:2 * dd], None, False, False, batch=K - 1, sA=N * Vp, sB=dd * Vp, sC=dd)
+            xf2 = dec["xf"].view(N, K * dd)
+            if train_other:
+                gah = m.block("audio_head.padded", True)
+                ops.gemm(xf2[:, dd:2 * dd], dl[0], gah[0], gah[0], True, True, batch=K - 1, sA=dd, sB=N * Vp,
+                         sC=dd * Vp, sR=dd * Vp)
+            del dl
+            dx0 = self.decoder.backward(dxf.view(N * K, dd), N, K, tr["decoder"], 1.0, on_layer_done=self.grad_hook)
+            dseq = torch.empty(N * K, d, dtype=BF16, device=dev)
+            ops.linear_dx(dx0, m.block("projection.weight"), dseq)
+            if train_other:
+                ops.linear_dw(dx0, dec["seq"], m.block("projection.weight", True), accumulate=True)
+            dhid_f32 = torch.zeros(M, d, dtype=F32, device=dev)
+            ops.decoder_input_bwd(dseq, dec["rows"], dec["codes"], dhid_f32, d_audio, V)
+            if self.grad_hook is not None:
+                self.grad_hook("decoder", -1)
+
+        # ---- codebook-0 head (semantic term)
+        dlog = torch.empty(M, Vp, dtype=BF16, device=dev)
+        rows_loss = torch.empty(M, dtype=F32, device=dev)
+        ops.ce_fwd_bwd(s["logits"], s["t0"], rows_loss, dlog, V, gscale * s["sw"] / s["n_sem"])
+        dhid = torch.empty(M, d, dtype=BF16, device=dev)
+        ops.linear_dx(dlog, m.block("codebook0_head.padded"), dhid)
+        if train_other:
+            ops.linear_dw(dlog, hidden, m.block("codebook0_head.padded", True), accumulate=True)
+        del dlog
+        if dhid_f32 is not None:
+            ops.add_f32_into_bf16(dhid, dhid_f32)
+        if self.grad_hook is not None:
+            self.grad_hook("other", -1)
+
+        # ---- backbone
+        dh0 = self.backbone.backward(dhid, B, S, tr["backbone"], 1.0, on_layer_done=self.grad_hook)
+        if train_embeddings:
+            ops.embed_bwd(s["tk"], s["mk"], dh0, d_text, d_audio, V)
+            ops.f32_to_bf16(d_text.view(-1), m.block("text_embeddings.weight", True).view(-1), accumulate=True)
+            ops.f32_to_bf16(d_audio.view(-1), m.block("audio_embeddings.weight", True).view(-1), accumulate=True)
+        if self.grad_hook is not None:
+            self.grad_hook("embeddings", -1)
+
+    # -------------------------------------------------------------------------------------------- generation
+    @torch.no_grad()
+    def hidden_states(self, tokens: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+        """Backbone hidden states [B, S, D] (bf16) for full sequences - used by generation and by parity tests."""
+        m, a = self.m, self.m.args
+        B, S, K1 = tokens.shape
+        M = B * S
+        tk = tokens.reshape(M, K1).to(device=m.device, dtype=torch.int64).contiguous()
+        mk = masks.reshape(M, K1).to(device=m.device, dtype=torch.uint8).contiguous()
+        h0 = torch.empty(M, m.bb.embed_dim, dtype=BF16, device=m.device)
+        ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, a.audio_vocab_size)
+        return self.backbone.forward(h0, B, S, False).view(B, S, -1)
+
+    @torch.no_grad()
+    def generate_frame(self, tokens, tokens_mask, input_pos, temperature, topk, noise=None):
+        """Reference model.py:140-195.  The KV state is the token history (prefix recompute)."""
+        m, a = self.m, self.m.args
+        dev = m.device
+        K, V, Vp = a.audio_num_codebooks, a.audio_vocab_size, m.vocab_pad
+        d, dd = m.bb.embed_dim, m.dc.embed_dim
+        tokens = tokens.to(dev)
+        tokens_mask = tokens_mask.to(dev)
+        first = int(input_pos[0, 0]) == 0
+        if first or m._gen_hist is None:
+            hist_t, hist_m = tokens, tokens_mask
+        else:
+            hist_t = torch.cat([m._gen_hist[0], tokens], dim=1)
+            hist_m = torch.cat([m._gen_hist[1], tokens_mask], dim=1)
+        m._gen_hist = (hist_t, hist_m)
+        Bn = hist_t.shape[0]
+        hidden = self.hidden_states(hist_t, hist_m)                 # [B, S, d]
+        last_h = hidden[:, -1, :].contiguous()                      # [B, d]
+        logits = torch.empty(Bn, Vp, dtype=F32, device=dev)
+        ops.linear_fwd(last_h, m.block("codebook0_head.padded"), logits)
+        from .models.model import sample_topk
+
+        def draw(lg, i):
+            q = None if noise is None else noise[i].to(dev)
+            return sample_topk(lg[:, :V], topk, temperature, q)
+
+        c0 = draw(logits, 0)                                         # [B,1] int32
+        samples = [c0]
+        aemb = m.block("audio_embeddings.weight")
+        seq = [last_h.unsqueeze(1), aemb[c0.long() + 0 * V]]        # [B,1,d] each
+        ah = m.block("audio_head.padded")
+        for i in range(1, K):
+            cur = torch.cat(seq, dim=1)                              # [B, L, d]
+            L = cur.shape[1]
+            x0 = torch.empty(Bn * L, dd, dtype=BF16, device=dev)
+            ops.linear_fwd(cur.reshape(Bn * L, d).contiguous(), m.block("projection.weight"), x0)
+            xf = self.decoder.forward(x0, Bn, L, False).view(Bn, L, dd)
+            lg = torch.empty(Bn, Vp, dtype=F32, device=dev)
+            ops.gemm(xf[:, -1, :].contiguous(), ah[i - 1], lg, None, False, True)
+            ci = draw(lg, i)
+            samples.append(ci)
+            seq.append(aemb[ci.long() + i * V])
+        return torch.cat(samples, dim=1)

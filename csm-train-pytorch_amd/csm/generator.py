@@ -1,0 +1,137 @@
+"""Generation API of reference ``src/csm/generator.py`` (``Segment``, ``Generator``, ``load_csm_1b``) on MI355X.
+
+The autoregressive core (``Model.generate_frame`` driven by ``Generator.generate``, generator.py:147-218) and the frame
+tokenisation (generator.py:77-145) are implemented here.  Two inputs of the reference cannot exist in this build
+environment (no network): the Llama-3 text tokenizer (``AutoTokenizer.from_pretrained``, generator.py:35-36) and the
+Mimi codec weights (``hf_hub_download``, generator.py:67).  Both are therefore *injected*: ``Generator(model,
+text_tokenizer=..., audio_tokenizer=...)``; when omitted the reference's own loading calls are attempted and their
+failure is reported as-is.  The audio tokenizer protocol is Mimi's: ``encode([1,1,N]) -> [1,K,T]`` int64,
+``decode([1,K,T]) -> [1,1,N]``, ``sample_rate``.  Watermarking (silentcipher) is post-processing outside the hot path
+and is not applied here (out of scope).
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from .models.model import Model, ModelArgs
+
+
+@dataclass
+class Segment:
+    """A segment of speech (reference generator.py:18-25)."""
+
+    speaker: int
+    text: str
+    audio: torch.Tensor  # (num_samples,), sample_rate = 24_000
+
+
+def load_llama3_tokenizer():
+    """Reference generator.py:28-45 (needs the Hugging Face hub or a local cache of meta-llama/Llama-3.2-1B)."""
+    from tokenizers.processors import TemplateProcessing
+    from transformers import AutoTokenizer
+
+    tokenizer = AutoTokenizer.from_pretrained("meta-llama/Llama-3.2-1B")
+    bos, eos = tokenizer.bos_token, tokenizer.eos_token
+    tokenizer._tokenizer.post_processor = TemplateProcessing(
+        single=f"{bos}:0 $A:0 {eos}:0", pair=f"{bos}:0 $A:0 {eos}:0 {bos}:1 $B:1 {eos}:1",
+        special_tokens=[(f"{bos}", tokenizer.bos_token_id), (f"{eos}", tokenizer.eos_token_id)])
+    return tokenizer
+
+
+class Generator:
+    """Speech generator using the CSM model (reference generator.py:48)."""
+
+    def __init__(self, model: Model, text_tokenizer=None, audio_tokenizer=None):
+        self._model = model
+        self._model.setup_caches(1)
+        self._text_tokenizer = text_tokenizer if text_tokenizer is not None else load_llama3_tokenizer()
+        if audio_tokenizer is None:
+            raise RuntimeError("Generator needs an audio tokenizer with Mimi's encode/decode protocol: the reference fetches "
+                               "Mimi weights from the hub (generator.py:67), which this environment cannot do")
+        self._audio_tokenizer = audio_tokenizer
+        self.sample_rate = audio_tokenizer.sample_rate
+        self.device = model.device
+
+    def _tokenize_text_segment(self, text: str, speaker: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Reference generator.py:77-100: ``f"[{speaker}]{text}"`` ids into the last column."""
+        K1 = self._model.args.audio_num_codebooks + 1
+        ids = self._text_tokenizer.encode(f"[{speaker}]{text}")
+        frame = torch.zeros(len(ids), K1).long()
+        mask = torch.zeros(len(ids), K1).bool()
+        frame[:, -1] = torch.tensor(ids)
+        mask[:, -1] = True
+        return frame.to(self.device), mask.to(self.device)
+
+    def _tokenize_audio(self, audio: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Reference generator.py:102-130: Mimi codes [K,T] + one all-zero EOS frame into the first K columns."""
+        K1 = self._model.args.audio_num_codebooks + 1
+        audio = audio.to(self.device)
+        codes = self._audio_tokenizer.encode(audio.unsqueeze(0).unsqueeze(0))[0]
+        eos = torch.zeros(codes.size(0), 1, dtype=codes.dtype, device=codes.device)
+        codes = torch.cat([codes, eos], dim=1)
+        frame = torch.zeros(codes.size(1), K1).long().to(self.device)
+        mask = torch.zeros(codes.size(1), K1).bool().to(self.device)
+        frame[:, :-1] = codes.transpose(0, 1)
+        mask[:, :-1] = True
+        return frame, mask
+
+    def _tokenize_segment(self, segment: Segment) -> Tuple[torch.Tensor, torch.Tensor]:
+        tt, tm = self._tokenize_text_segment(segment.text, segment.speaker)
+        at, am = self._tokenize_audio(segment.audio)
+        return torch.cat([tt, at], dim=0), torch.cat([tm, am], dim=0)
+
+    @torch.inference_mode()
+    def generate(self, text: str, speaker: int, context: List[Segment], max_audio_length_ms: float = 90_000,
+                 temperature: float = 0.9, topk: int = 50) -> torch.Tensor:
+        """Reference generator.py:147-218."""
+        self._model.reset_caches()
+        max_audio_frames = int(max_audio_length_ms / 80)
+        tokens, masks = [], []
+        for seg in context:
+            t, m = self._tokenize_segment(seg)
+            tokens.append(t)
+            masks.append(m)
+        t, m = self._tokenize_text_segment(text, speaker)
+        tokens.append(t)
+        masks.append(m)
+        prompt_tokens = torch.cat(tokens, dim=0).long().to(self.device)
+        prompt_mask = torch.cat(masks, dim=0).bool().to(self.device)
+        samples = []
+        curr_tokens, curr_mask = prompt_tokens.unsqueeze(0), prompt_mask.unsqueeze(0)
+        curr_pos = torch.arange(0, prompt_tokens.size(0)).unsqueeze(0).long().to(self.device)
+        max_seq_len = self._model.bb.max_seq_len - max_audio_frames
+        if curr_tokens.size(1) >= max_seq_len:
+            raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_seq_len}")
+        K = self._model.args.audio_num_codebooks
+        for _ in range(max_audio_frames):
+            sample = self._model.generate_frame(curr_tokens, curr_mask, curr_pos, temperature, topk)
+            if torch.all(sample == 0):
+                break  # eos
+            samples.append(sample)
+            curr_tokens = torch.cat([sample.long(), torch.zeros(1, 1).long().to(self.device)], dim=1).unsqueeze(1)
+            curr_mask = torch.cat([torch.ones(1, K).bool().to(self.device), torch.zeros(1, 1).bool().to(self.device)], dim=1).unsqueeze(1)
+            curr_pos = curr_pos[:, -1:] + 1
+        if not samples:
+            return torch.zeros(0, device=self.device)
+        codes = torch.stack(samples).permute(1, 2, 0).long()
+        return self._audio_tokenizer.decode(codes).squeeze(0).squeeze(0)
+
+    def save_wav(self, path: str, audio: torch.Tensor):
+        """16-bit PCM writer (torchaudio is not available in this image)."""
+        import wave
+        pcm = (audio.detach().float().cpu().clamp(-1, 1) * 32767.0).to(torch.int16).numpy().tobytes()
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(int(self.sample_rate))
+            w.writeframes(pcm)
+
+
+def load_csm_1b(ckpt_path: str = "ckpt.pt", device: str = "cuda", text_tokenizer=None, audio_tokenizer=None) -> Generator:
+    """Reference generator.py:221-244."""
+    args = ModelArgs(backbone_flavor="llama-1B", decoder_flavor="llama-100M", text_vocab_size=128256,
+                     audio_vocab_size=2051, audio_num_codebooks=32)
+    model = Model(args, device=device)
+    model.load_state_dict(torch.load(ckpt_path, map_location="cpu", weights_only=False))
+    return Generator(model, text_tokenizer=text_tokenizer, audio_tokenizer=audio_tokenizer)

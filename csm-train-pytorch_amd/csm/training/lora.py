@@ -1,0 +1,130 @@
+"""LoRA adapters for the HIP path.  Semantics of reference ``src/csm/mlx/components/lora.py``:
+
+  y = x W0^T + (alpha / r) * ((x A^T) B^T),  A ~ N(0, 1/sqrt(in)) of shape [r, in],  B = 0 of shape [out, r]
+  (``LoRALinear`` lora.py:14-105), merge W0 + (alpha/r) B A (lora.py:140-153), applied to both stacks, default
+  target modules ["q_proj", "v_proj"], all layers unless ``target_layers`` (``apply_lora_to_model`` lora.py:741-860).
+
+Names are ``{backbone|decoder}.layers.{i}.attn.{q_proj,k_proj,v_proj,output_proj}.lora_{A,B}`` and
+``...mlp.{w1,w2,w3}.lora_{A,B}``; the stack prefix fixes the reference's key collision between backbone and decoder
+adapters.  The four skinny products per adapter go through the same MFMA GEMM as everything
+else (N or K = r = 8), accumulating into the frozen projection's output / input gradient in the GEMM epilogue.
+"""
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+
+from ..hip import ops
+
+BF16 = torch.bfloat16
+ATTN = ("q_proj", "k_proj", "v_proj", "output_proj")
+MLP = ("w1", "w2", "w3")
+
+
+class LoRAAdapter:
+    def __init__(self, name, A, B, gA, gB, scaling):
+        self.name, self.A, self.B, self.gA, self.gB, self.scaling = name, A, B, gA, gB, scaling
+        self.r = A.shape[0]
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """y += scaling * (x A^T) B^T ; returns t = x A^T (kept for the backward)."""
+        t = torch.empty(x.shape[0], self.r, dtype=BF16, device=x.device)
+        ops.gemm(x, self.A, t)
+        ops.gemm(t, self.B, y, y, alpha=self.scaling)
+        return t
+
+    def backward(self, x, dy, t, dx):
+        """dB += s dy^T t ; dt = s dy B ; dA += dt^T x ; dx += dt A."""
+        dt = torch.empty_like(t)
+        ops.gemm(dy, self.B, dt, None, False, True, alpha=self.scaling)
+        ops.gemm(dy, t, self.gB, self.gB, True, True, alpha=self.scaling)
+        ops.gemm(dt, x, self.gA, self.gA, True, True)
+        ops.gemm(dt, self.A, dx, dx, False, True)
+
+
+class LoRAState:
+    """All adapters of a model in one bf16 arena (+ gradient arena)."""
+
+    def __init__(self, model, r: int, alpha: float, dropout: float, target_modules: List[str],
+                 target_layers: Optional[List[int]], use_bias: bool, seed: int = 0):
+        if dropout and dropout > 0:
+            raise NotImplementedError("lora_dropout > 0 is not implemented on the HIP path yet")
+        if use_bias:
+            raise NotImplementedError("lora_use_bias is not implemented on the HIP path yet")
+        if r % 8 != 0:
+            raise ValueError("lora_r must be a multiple of 8 (MFMA k-step / 16-byte rows)")
+        self.r, self.alpha, self.dropout, self.scaling = r, alpha, dropout, alpha / r
+        self.target_modules, self.target_layers, self.use_bias = list(target_modules), target_layers, use_bias
+        plan = []
+        for prefix, c in (("backbone", model.bb), ("decoder", model.dc)):
+            hq, hk = c.num_heads * c.head_dim, c.num_kv_heads * c.head_dim
+            dims = {"q_proj": (hq, c.embed_dim), "k_proj": (hk, c.embed_dim), "v_proj": (hk, c.embed_dim),
+                    "output_proj": (c.embed_dim, c.embed_dim), "w1": (c.intermediate_dim, c.embed_dim),
+                    "w3": (c.intermediate_dim, c.embed_dim), "w2": (c.embed_dim, c.intermediate_dim)}
+            for i in range(c.num_layers):
+                if target_layers is not None and i not in target_layers:
+                    continue
+                for mod in target_modules:
+                    if mod not in dims:
+                        raise ValueError(f"unknown LoRA target module {mod!r}")
+                    sub = "attn" if mod in ATTN else "mlp"
+                    out_f, in_f = dims[mod]
+                    plan.append((prefix, i, mod, f"{prefix}.layers.{i}.{sub}.{mod}", out_f, in_f))
+        total = sum(r * in_f + out_f * r for *_, out_f, in_f in plan)
+        total = (total + 7) // 8 * 8
+        dev = model.device
+        self.arena = torch.zeros(total, dtype=BF16, device=dev)
+        self.grad_arena = torch.zeros(total, dtype=BF16, device=dev)
+        self.adapters: Dict[tuple, LoRAAdapter] = OrderedDict()
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        off = 0
+        for prefix, i, mod, name, out_f, in_f in plan:
+            A = self.arena[off:off + r * in_f].view(r, in_f)
+            gA = self.grad_arena[off:off + r * in_f].view(r, in_f)
+            off += r * in_f
+            B = self.arena[off:off + out_f * r].view(out_f, r)
+            gB = self.grad_arena[off:off + out_f * r].view(out_f, r)
+            off += out_f * r
+            A.copy_((torch.randn(r, in_f, generator=g, device=dev) / math.sqrt(in_f)).to(BF16))
+            self.adapters[(prefix, i, mod)] = LoRAAdapter(name, A, B, gA, gB, self.scaling)
+
+    def get(self, prefix, layer, module):
+        return self.adapters.get((prefix, layer, module))
+
+    def named_tensors(self):
+        for ad in self.adapters.values():
+            yield f"{ad.name}.lora_A", ad.A
+            yield f"{ad.name}.lora_B", ad.B
+
+    def num_params(self) -> int:
+        return sum(ad.A.numel() + ad.B.numel() for ad in self.adapters.values())
+
+
+def apply_lora_to_model(model, r: int = 8, alpha: float = 16.0, dropout: float = 0.0,
+                        target_modules: Optional[List[str]] = None, target_layers: Optional[List[int]] = None,
+                        use_bias: bool = False, seed: int = 0):
+    """Reference ``apply_lora_to_model`` (lora.py:741-860): freezes the base model, attaches adapters, and gives the
+    model ``get_lora_params()`` / ``merge_lora_weights()``."""
+    if target_modules is None:
+        target_modules = ["q_proj", "v_proj"]     # reference default, lora.py:801-803
+    model.lora = LoRAState(model, r, alpha, dropout, target_modules, target_layers, use_bias, seed)
+    for k in model.trainable:
+        model.trainable[k] = False
+    model.get_lora_params = lambda: OrderedDict(model.lora.named_tensors())
+    model.merge_lora_weights = lambda: merge_lora_weights(model)
+    return model
+
+
+@torch.no_grad()
+def merge_lora_weights(model):
+    """W0 += (alpha/r) * B A for every adapter (reference ``merge_with_base`` lora.py:140-153), on the GPU via the
+    same GEMM (C = B[out,r] . (A[r,in] read as [K=r][N=in]) + C).  Returns the model."""
+    lo = model.lora
+    views = model._views(model.arena)
+    for (prefix, i, mod), ad in lo.adapters.items():
+        sub = "attn" if mod in ATTN else "mlp"
+        W = views[f"{prefix}.layers.{i}.{sub}.{mod}.weight"]
+        ops.gemm(ad.B, ad.A, W, W, False, True, alpha=lo.scaling)
+    return model

@@ -1,0 +1,230 @@
+"""End-to-end parity of the HIP train / generate path against the CPU oracle and the committed golden fixtures.
+
+Tolerances (stated per north_star): loss within 1e-3 relative of the fp32 CPU path *on the same (bf16-representable)
+weights*; gradients (bf16 storage, bf16 activations) within 3e-2 of the tensor's max magnitude; sampled codebook
+indices bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csm_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TINY = O.tiny_cfg()
+
+
+def tiny_model(dev, seed=11):
+    from csm.models.model import Model, ModelArgs
+    m = Model(ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", TINY.text_vocab, TINY.audio_vocab, TINY.n_codebooks), device="cuda")
+    p32 = O.init_params(TINY, seed=seed)
+    m.load_state_dict(p32)
+    # what the GPU really holds: bf16-rounded weights, as fp32 for the oracle
+    pq = {k: v.to(BF).float() for k, v in p32.items()}
+    return m, p32, pq
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(1e-12, abs(float(b)))
+
+
+def gclose(name, got, ref, tol=3e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-20
+    assert err <= tol * scale, f"{name}: max abs err {err:.4g} vs max |ref| {scale:.4g}"
+
+
+def test_state_dict_names_and_roundtrip(dev):
+    m, p32, pq = tiny_model(dev)
+    sd = m.state_dict()
+    assert list(sorted(sd.keys())) == sorted(p32.keys())
+    for k in p32:
+        assert tuple(sd[k].shape) == tuple(p32[k].shape), k
+        assert torch.equal(sd[k].float().cpu(), pq[k]), k
+    names = [n for n, _ in m.named_parameters()]
+    assert sorted(names) == sorted(p32.keys())
+
+
+def test_compute_loss_reference_mode(dev):
+    """Mode A: exactly the reference's loss (semantic CE x100, acoustic placeholder 0)."""
+    from csm.training.utils import compute_loss
+    m, p32, pq = tiny_model(dev)
+    z = np.load(os.path.join(GOLD, "golden_small.npz"))
+    meta = json.load(open(os.path.join(GOLD, "golden_meta.json")))
+    tokens, mask, targets = (torch.from_numpy(z[k]) for k in ("tokens", "mask", "targets"))
+    with torch.no_grad():
+        total, det = compute_loss(m, tokens, mask, targets, 100.0, 1.0)
+    ref_total, ref_det = O.compute_loss(pq, TINY, tokens, mask, targets, 100.0, 1.0, acoustic_rows="off")
+    assert rel(total, ref_total) < 1e-3, (float(total), float(ref_total))
+    assert float(det["acoustic_loss"]) == 0.0
+    # against the value the REFERENCE's own compute_loss produced in the build container (fp32 weights)
+    assert rel(total, meta["compute_loss_ref"]) < 3e-3, (float(total), meta["compute_loss_ref"])
+    # embedding kernel against the reference-pinned masked sum
+    B, S, K1 = tokens.shape
+    from csm.hip import ops
+    h0 = torch.empty(B * S, TINY.backbone.dim, dtype=BF, device=dev)
+    ops.embed_fwd(tokens.view(B * S, K1).to(dev), mask.view(B * S, K1).to(torch.uint8).to(dev),
+                  m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, TINY.audio_vocab)
+    gclose("embed vs reference", h0, torch.from_numpy(z["embed_sum"]).view(B * S, -1), 1e-2)
+
+
+def test_hidden_states_match_oracle(dev):
+    m, p32, pq = tiny_model(dev)
+    tokens, mask, _ = O.synthetic_batch(TINY, 2, 100, seed=3)
+    hid = m.engine.hidden_states(tokens, mask)
+    ref = O.backbone_hidden(pq, TINY, tokens, mask)
+    gclose("backbone hidden", hid, ref, 3e-2)
+
+
+def test_train_step_full(dev):
+    """Loss (semantic + teacher-forced acoustic on a row subset), gradients and one AdamW step vs the oracle."""
+    from csm.training.utils import compute_loss
+    from csm.training.optim import FusedAdamW
+    m, p32, pq = tiny_model(dev)
+    m.acoustic_mode = "all"
+    z = np.load(os.path.join(GOLD, "golden_small.npz"))
+    meta = json.load(open(os.path.join(GOLD, "golden_meta.json")))
+    tokens, mask, targets = (torch.from_numpy(z[k]) for k in ("tokens", "mask", "targets"))
+    B, S = tokens.shape[:2]
+    rows = torch.arange(0, B * (S - 1), meta["train_step"]["rows_stride"])
+    opt = FusedAdamW(m, {"backbone": 1e-3, "decoder": 1e-3, "embeddings": 1e-3, "other": 1e-3})
+    total, det = compute_loss(m, tokens, mask, targets, 100.0, 1.0, acoustic_rows=rows)
+    total.backward()
+    pt = {k: v.clone().requires_grad_(True) for k, v in pq.items()}
+    rt, rd = O.compute_loss(pt, TINY, tokens, mask, targets, 100.0, 1.0, acoustic_rows=rows)
+    rt.backward()
+    assert rel(det["semantic_loss"], rd["semantic_loss"]) < 1e-3
+    assert rel(det["acoustic_loss"], rd["acoustic_loss"]) < 1e-3
+    assert rel(total, rt) < 1e-3
+    assert rel(total, meta["train_step"]["total"]) < 3e-3          # fp32-weight value frozen in the fixture
+    grads = dict(m.named_parameters())
+    worst = 0.0
+    for k, p in pt.items():
+        g = grads[k].grad
+        assert g is not None, k
+        gclose(f"grad {k}", g, p.grad, 4e-2)
+    # fixture gradients (fp32 weights, first 64 columns) agree as well
+    for key in z.files:
+        if key.startswith("grad::"):
+            k = key[6:]
+            g = grads[k].grad.float().cpu()
+            ref = torch.from_numpy(z[key])
+            gclose(f"golden grad {k}", g[..., :64] if g.dim() > 1 else g, ref, 6e-2)
+    # clip + AdamW against the oracle restatement
+    norm = opt.clip_grad_norm(1.0)
+    ref_grads = [pt[k].grad.clone() for k in pt]
+    rn, coef = O.clip_grad_norm(ref_grads, 1.0)
+    assert rel(norm, rn) < 2e-2, (float(norm), float(rn))
+    opt.step()
+    masters = dict(opt.named_master())
+    assert sorted(masters) == sorted(pt)
+    for (k, p), g in zip(pt.items(), ref_grads):
+        pr = p.detach().clone()
+        O.adamw_step(pr, g, torch.zeros_like(pr), torch.zeros_like(pr), 1, 1e-3)
+        # step 1 moves every weight by ~lr*sign(g) (+ decay): compare the fp32 master where the gradient is not ~0
+        upd, upd_ref = masters[k].float().cpu() - pq[k], pr - pq[k]
+        big = g.abs() > 1e-2 * g.abs().max()
+        if big.any():
+            assert (upd[big] - upd_ref[big]).abs().max().item() < 1e-4, k
+        # the bf16 working copy is the rounded master
+        assert torch.equal(dict(m.named_parameters())[k].detach().float().cpu(), masters[k].to(BF).float().cpu()), k
+
+
+def test_grad_accumulation_and_freeze(dev):
+    from csm.training.utils import compute_loss
+    m, _, _ = tiny_model(dev)
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=5)
+    m.ensure_grads()
+    t1, _ = compute_loss(m, tokens, mask, targets)
+    (t1 / 2).backward()
+    g1 = m.grad_arena.clone()
+    t2, _ = compute_loss(m, tokens, mask, targets)
+    (t2 / 2).backward()
+    gclose("two half steps == one full", m.grad_arena, 2 * g1.float(), 2e-2)
+    m.grad_arena.zero_()
+    m.trainable.update(backbone=False, embeddings=False)
+    t3, _ = compute_loss(m, tokens, mask, targets)
+    t3.backward()
+    o, n = m.group_range("backbone")
+    assert float(m.grad_arena[o:o + n].abs().max()) == 0.0
+    o, n = m.group_range("other")
+    assert float(m.grad_arena[o:o + n].abs().max()) > 0.0
+
+
+def test_lora_step(dev):
+    from csm.training.lora import apply_lora_to_model, merge_lora_weights
+    from csm.training.utils import compute_loss
+    m, p32, pq = tiny_model(dev)
+    m.acoustic_mode = "all"
+    apply_lora_to_model(m, r=8, alpha=16.0, target_modules=["q_proj", "v_proj", "w2"], seed=1)
+    with torch.no_grad():   # make B non-zero so that every gradient path is exercised
+        g = torch.Generator(device=dev).manual_seed(2)
+        for ad in m.lora.adapters.values():
+            ad.B.copy_((torch.randn(ad.B.shape, generator=g, device=dev) * 0.05).to(BF))
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=6)
+    total, det = compute_loss(m, tokens, mask, targets)
+    total.backward()
+    lora = {k: v.detach().float().cpu().requires_grad_(True) for k, v in m.get_lora_params().items()}
+    rt, _ = O.compute_loss(pq, TINY, tokens, mask, targets, acoustic_rows=None, lora=lora, lora_scaling=2.0)
+    rt.backward()
+    assert rel(total, rt) < 1e-3, (float(total), float(rt))
+    for ad in m.lora.adapters.values():
+        gclose(f"{ad.name}.lora_A grad", ad.gA, lora[f"{ad.name}.lora_A"].grad, 5e-2)
+        gclose(f"{ad.name}.lora_B grad", ad.gB, lora[f"{ad.name}.lora_B"].grad, 5e-2)
+    assert m.grad_arena is None or float(m.grad_arena.abs().max()) == 0.0, "base weights are frozen"
+    # merged weights reproduce the adapted forward
+    with torch.no_grad():
+        before, _ = compute_loss(m, tokens, mask, targets)
+        merge_lora_weights(m)
+        m.lora = None
+        after, _ = compute_loss(m, tokens, mask, targets)
+    assert rel(after, before) < 2e-3
+
+
+def test_generate_frame_matches_reference_fixture(dev):
+    """Frames sampled by the REFERENCE's generate_frame (fp32, stand-in stacks) for fixed noise: indices bit-exact."""
+    m, p32, pq = tiny_model(dev)
+    meta = json.load(open(os.path.join(GOLD, "golden_meta.json")))
+    z = np.load(os.path.join(GOLD, "golden_small.npz"))
+    tokens, mask = torch.from_numpy(z["tokens"]), torch.from_numpy(z["mask"])
+    K = TINY.n_codebooks
+    m.setup_caches(1)
+    n_prompt = 9
+    cur_t, cur_m, cur_p = tokens[:1, :n_prompt], mask[:1, :n_prompt], torch.arange(n_prompt).unsqueeze(0)
+    got = []
+    for step in range(3):
+        torch.manual_seed(1000 + step)
+        qs = [torch.empty(1, TINY.audio_vocab).exponential_(1) for _ in range(K)]
+        f = m.generate_frame(cur_t, cur_m, cur_p, 0.9, 10, noise=qs).cpu()
+        got.append(f[0].tolist())
+        cur_t = torch.cat([f.long(), torch.zeros(1, 1, dtype=torch.long)], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones(1, K, dtype=torch.bool), torch.zeros(1, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
+        cur_p = cur_p[:, -1:] + 1
+    assert got == meta["generate_frames"], (got, meta["generate_frames"])
+
+
+def test_checkpoint_roundtrip(dev, tmp_path):
+    from csm.training.optim import FusedAdamW
+    from csm.training.utils import compute_loss, load_checkpoint, save_checkpoint
+    m, _, _ = tiny_model(dev)
+    opt = FusedAdamW(m, {"backbone": 1e-3, "decoder": 1e-3, "embeddings": 1e-3, "other": 1e-3})
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=5)
+    t, _ = compute_loss(m, tokens, mask, targets)
+    t.backward()
+    opt.step()
+    path = save_checkpoint(m, opt, 1, 7, float(t), str(tmp_path))
+    assert os.path.exists(path) and os.path.exists(os.path.join(str(tmp_path), "checkpoint_latest.pt"))
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch", "global_step", "loss"}
+    m2, _, _ = tiny_model(dev, seed=99)
+    opt2 = FusedAdamW(m2, {"backbone": 1e-3, "decoder": 1e-3, "embeddings": 1e-3, "other": 1e-3})
+    meta = load_checkpoint(path, m2, opt2)
+    assert meta["epoch"] == 1 and meta["global_step"] == 7
+    assert torch.equal(m2.arena, m.arena)
+    assert torch.equal(opt2.state["backbone"]["m"], opt.state["backbone"]["m"])
