@@ -79,6 +79,35 @@ __device__ __forceinline__ void stage_store(char* lds, const U4 (&reg)[4]) {
     }
 }
 
+// direct global->LDS staging (LDS-DMA, 16 B per lane, 1 KiB per wave-instruction).  The LDS destination is
+// wave-uniform base + lane*16, so the XOR swizzle is applied to the per-lane SOURCE address and the image is the
+// same one stage_store writes.  No zero fill: callers guarantee K % 64 == 0; row/column overhang is clamped.
+template <int T>
+__device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0, char* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i;  // 1-KiB piece of the 16-KiB tile
+        const bf16_t* src;
+        if (T == 0) {
+            const int r = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            int gr = row0 + r;
+            gr = gr < rows ? gr : rows - 1;
+            src = P + (size_t)gr * ld + k0 + c * 8;
+        } else {
+            const int kr = 4 * j + (lane >> 4);
+            const int u = lane & 15;
+            const int sl = (u >> 1) ^ (kr & 7);
+            int gc = row0 + sl * 16 + (u & 1) * 8;
+            gc = gc < rows ? gc : rows - 8;
+            src = P + (size_t)(k0 + kr) * ld + gc;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
+    }
+}
+
 // fragment of 16 tile-rows starting at r0 for k-step ks (32 deep) -> lane holds row (lane&15), k = 8*(lane>>4)+j
 template <int T>
 __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int ks, int lane) {
@@ -97,7 +126,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int ks, int
     }
 }
 
-template <int TA, int TB, typename OutT>
+template <int TA, int TB, typename OutT, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- XCD-aware, GROUP_M-rastered tile id -------------------------------------------------
@@ -132,20 +161,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     auto ldsA = [&](int b) { return smem + b * 2 * TILE_BYTES; };
     auto ldsB = [&](int b) { return smem + b * 2 * TILE_BYTES + TILE_BYTES; };
 
-    U4 ra[4], rb[4];
     const int nt = (g.K + BK - 1) / BK;
-    stage_load<TA>(A, g.lda, g.M, g.K, m0, 0, ra);
-    stage_load<TB>(B, g.ldb, g.N, g.K, n0, 0, rb);
-    stage_store<TA>(ldsA(0), ra);
-    stage_store<TB>(ldsB(0), rb);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) {
-            stage_load<TA>(A, g.lda, g.M, g.K, m0, (t + 1) * BK, ra);
-            stage_load<TB>(B, g.ldb, g.N, g.K, n0, (t + 1) * BK, rb);
-        }
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -159,11 +176,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nt) {
-            stage_store<TA>(ldsA(cur ^ 1), ra);
-            stage_store<TB>(ldsB(cur ^ 1), rb);
+    };
+    if constexpr (GLDS) {
+        stage_glds<TA>(A, g.lda, g.M, m0, 0, ldsA(0));
+        stage_glds<TB>(B, g.ldb, g.N, n0, 0, ldsB(0));
+        __syncthreads();   // waits vmcnt(0) for the LDS-DMA, then the barrier
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt) {
+                stage_glds<TA>(A, g.lda, g.M, m0, (t + 1) * BK, ldsA(cur ^ 1));
+                stage_glds<TB>(B, g.ldb, g.N, n0, (t + 1) * BK, ldsB(cur ^ 1));
+            }
+            compute(cur);
+            __syncthreads();
         }
+    } else {
+        U4 ra[4], rb[4];
+        stage_load<TA>(A, g.lda, g.M, g.K, m0, 0, ra);
+        stage_load<TB>(B, g.ldb, g.N, g.K, n0, 0, rb);
+        stage_store<TA>(ldsA(0), ra);
+        stage_store<TB>(ldsB(0), rb);
         __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt) {
+                stage_load<TA>(A, g.lda, g.M, g.K, m0, (t + 1) * BK, ra);
+                stage_load<TB>(B, g.ldb, g.N, g.K, n0, (t + 1) * BK, rb);
+            }
+            compute(cur);
+            if (t + 1 < nt) {
+                stage_store<TA>(ldsA(cur ^ 1), ra);
+                stage_store<TB>(ldsB(cur ^ 1), rb);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] per 16x16 tile ----------
@@ -205,17 +251,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+int g_gemm_variant = 1;   // 0 = register staging everywhere, 1 = LDS-DMA staging when K % 64 == 0
+
 template <int TA, int TB>
 int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
     dim3 grid(g.tiles_m * g.tiles_n, 1, batch), block(256);
     const size_t lds = 4 * TILE_BYTES;
-    if (out_f32) hipLaunchKernelGGL((gemm_kernel<TA, TB, float>), grid, block, lds, stream, g);
-    else hipLaunchKernelGGL((gemm_kernel<TA, TB, bf16_t>), grid, block, lds, stream, g);
+    const bool glds = g_gemm_variant >= 1 && (g.K % BK) == 0 && g.M >= 8 && g.N >= 8;
+    if (glds) {
+        if (out_f32) hipLaunchKernelGGL((gemm_kernel<TA, TB, float, true>), grid, block, lds, stream, g);
+        else hipLaunchKernelGGL((gemm_kernel<TA, TB, bf16_t, true>), grid, block, lds, stream, g);
+    } else {
+        if (out_f32) hipLaunchKernelGGL((gemm_kernel<TA, TB, float, false>), grid, block, lds, stream, g);
+        else hipLaunchKernelGGL((gemm_kernel<TA, TB, bf16_t, false>), grid, block, lds, stream, g);
+    }
     CSM_CHECK_LAUNCH("csm_gemm_bf16");
     return 0;
 }
 
 }  // namespace
+
+// tuning / A-B switch used by tools/gemm_bench.py: 0 = register staging, 1 = LDS-DMA staging (default)
+extern "C" int csm_set_gemm_variant(int v) {
+    g_gemm_variant = v;
+    return 0;
+}
 
 extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
                              int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,

@@ -40,6 +40,9 @@ int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, i
                   int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long strideA,
                   long long strideB, long long strideC, long long strideR, csm_stream_t stream);
 
+/* tuning switch (A/B benchmarking): 0 = register staging, 1 = LDS-DMA staging when K % 64 == 0 (default) */
+int csm_set_gemm_variant(int v);
+
 /* ---- K2: torchtune RMSNorm (sa_norm / mlp_norm / norm; eps=1e-5 at model.py:22,39) -------------------------- */
 int csm_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int M, int D, float eps, csm_stream_t stream);
 int csm_rmsnorm_bwd_blocks(void);
