@@ -17,114 +17,14 @@
 // ds_read_b128 row fragments (kc) and the ds_read_b64_tr_b16 transposed fragments (ks) are
 // bank-conflict free:
 //   kc image [128 rows][64 k]   : 16-B chunk c of row r lives at chunk  c ^ (r & 7)
-//   ks image [64 k][128 cols]   : 32-B slot  s of k-row r lives at slot s ^ (r & 7)
+//   ks image [64 k][128 cols]   : 32-B slot  s of k-row r lives at slot s ^ ks_swz(r)
 // The MFMA is issued with the operands swapped (D = Btile . Atile^T) so every lane ends up with
 // four CONSECUTIVE output columns of one row: 8-byte bf16 / 16-byte fp32 stores, no LDS epilogue.
 // Workgroup ids are remapped so that each XCD (private 4 MiB L2) walks a contiguous, GROUP_M-rastered
 // run of tiles.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
-
-struct GemmArgs {
-    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* R;
-    int M, N, K, lda, ldb, ldc, ldr;
-    long long sA, sB, sC, sR;  // batch strides in elements
-    float alpha;
-    int tiles_m, tiles_n;
-};
-
-// ---- staging: each thread moves 4 x 16 B per operand per K-tile --------------------------------
-template <int T>
-__device__ __forceinline__ void stage_load(const bf16_t* __restrict__ P, int ld, int rows /*M or N*/, int K,
-                                           int row0, int k0, U4 (&reg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = t + 256 * i;
-        U4 v = {0u, 0u, 0u, 0u};
-        if (T == 0) {
-            const int r = idx >> 3, c = idx & 7;
-            int gr = row0 + r;
-            gr = gr < rows ? gr : rows - 1;                 // clamp: garbage rows are masked at the store
-            const int gk = k0 + c * 8;
-            if (gk < K) v = *reinterpret_cast<const U4*>(P + (size_t)gr * ld + gk);
-        } else {
-            const int kr = idx >> 4, c = idx & 15;
-            const int gk = k0 + kr, gc = row0 + c * 8;
-            if (gk < K && gc < rows) v = *reinterpret_cast<const U4*>(P + (size_t)gk * ld + gc);
-        }
-        reg[i] = v;
-    }
-}
-
-template <int T>
-__device__ __forceinline__ void stage_store(char* lds, const U4 (&reg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = t + 256 * i;
-        int off;
-        if (T == 0) {
-            const int r = idx >> 3, c = idx & 7;
-            off = r * 128 + ((c ^ (r & 7)) << 4);
-        } else {
-            const int kr = idx >> 4, c = idx & 15;
-            off = kr * 256 + ((((c >> 1) ^ (kr & 7)) << 5) | ((c & 1) << 4));
-        }
-        *reinterpret_cast<U4*>(lds + off) = reg[i];
-    }
-}
-
-// direct global->LDS staging (LDS-DMA, 16 B per lane, 1 KiB per wave-instruction).  The LDS destination is
-// wave-uniform base + lane*16, so the XOR swizzle is applied to the per-lane SOURCE address and the image is the
-// same one stage_store writes.  No zero fill: callers guarantee K % 64 == 0; row/column overhang is clamped.
-template <int T>
-__device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0, char* lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = wave * 4 + i;  // 1-KiB piece of the 16-KiB tile
-        const bf16_t* src;
-        if (T == 0) {
-            const int r = 8 * j + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
-            int gr = row0 + r;
-            gr = gr < rows ? gr : rows - 1;
-            src = P + (size_t)gr * ld + k0 + c * 8;
-        } else {
-            const int kr = 4 * j + (lane >> 4);
-            const int u = lane & 15;
-            const int sl = (u >> 1) ^ (kr & 7);
-            int gc = row0 + sl * 16 + (u & 1) * 8;
-            gc = gc < rows ? gc : rows - 8;
-            src = P + (size_t)(k0 + kr) * ld + gc;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
-    }
-}
-
-// fragment of 16 tile-rows starting at r0 for k-step ks (32 deep) -> lane holds row (lane&15), k = 8*(lane>>4)+j
-template <int T>
-__device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int ks, int lane) {
-    if (T == 0) {
-        const int r = r0 + (lane & 15);
-        const int c = ks * 4 + (lane >> 4);
-        return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ (r & 7)) << 4));
-    } else {
-        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-        const int kr0 = ks * 32 + 8 * g + q;       // rows kr0 (+4 for the second half)
-        const int slot = r0 >> 4;
-        const int kr1 = kr0 + 4;
-        bf16x4 lo = lds_read_tr16(lds + kr0 * 256 + ((slot ^ (kr0 & 7)) << 5) + p * 8);
-        bf16x4 hi = lds_read_tr16(lds + kr1 * 256 + ((slot ^ (kr1 & 7)) << 5) + p * 8);
-        return cat4(lo, hi);
-    }
-}
 
 template <int TA, int TB, typename OutT, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
@@ -163,19 +63,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
     const int nt = (g.K + BK - 1) / BK;
     auto compute = [&](int cur) {
+        Frags<TA, 4> fa;
+        Frags<TB, 4> fb;
+        fa.load(ldsA(cur), wm0, lane);
+        fb.load(ldsB(cur), wn0, lane);
+        if constexpr (TA != 0 || TB != 0) frag_wait();   // asm tr-reads are invisible to hipcc's lgkmcnt bookkeeping
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = load_frag<TA>(ldsA(cur), wm0 + 16 * i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = load_frag<TB>(ldsB(cur), wn0 + 16 * j, ks, lane);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), fa.get(i, ks), acc[i][j], 0, 0, 0);
     };
     if constexpr (GLDS) {
         stage_glds<TA>(A, g.lda, g.M, m0, 0, ldsA(0));
@@ -251,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
-int g_gemm_variant = 1;   // 0 = register staging everywhere, 1 = LDS-DMA staging when K % 64 == 0
+int g_gemm_variant = 2;   // 0 register staging, 1 LDS-DMA 128x128, 2 auto (256x256 where it fills the chip), 3 force 256x256
 
 template <int TA, int TB>
 int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
@@ -271,7 +170,22 @@ int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
 
 }  // namespace
 
-// tuning / A-B switch used by tools/gemm_bench.py: 0 = register staging, 1 = LDS-DMA staging (default)
+int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                       int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
+                       long long sC, long long sR, hipStream_t stream);
+
+// 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
+// the 256 CUs and little of the tile area hangs over the matrix edge.
+static bool prefer_256(int M, int N, int K, int batch) {
+    if (K % 64 != 0 || M < 8 || N < 8) return false;
+    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+    const long long rounds = (tiles + 255) / 256;
+    const double fill = (double)tiles / (double)(rounds * 256);
+    const double area = ((double)M * N * batch) / ((double)tiles * 65536.0);
+    return fill * area >= 0.80;
+}
+
+// tuning / A-B switch used by tools/gemm_bench.py: 0 register staging, 1 LDS-DMA 128x128, 2 auto (default), 3 force 256x256
 extern "C" int csm_set_gemm_variant(int v) {
     g_gemm_variant = v;
     return 0;
@@ -291,6 +205,9 @@ extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* 
     if (!transB) CSM_REQUIRE((K & 7) == 0, "csm_gemm_bf16: K must be a multiple of 8 when B is [N][K] (K=%d)", K);
     else CSM_REQUIRE((N & 7) == 0, "csm_gemm_bf16: N must be a multiple of 8 when B is [K][N] (N=%d)", N);
     CSM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, "csm_gemm_bf16: leading dimension too small");
+    if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 3 && K % 64 == 0 && M >= 8 && N >= 8))
+        return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
+                                  strideB, strideC, strideR, stream);
     GemmArgs g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;

@@ -1,0 +1,221 @@
+// 256x256x64 deep-pipelined bf16 MFMA GEMM for gfx950 (same contract and operand layouts as gemm.hip).
+//
+// 512 threads = 8 waves as 2(M) x 4(N); each wave owns a 128x64 output block = 8x4 accumulators of
+// mfma_f32_16x16x32_bf16 (128 VGPRs).  LDS = 128 KiB = 2 K-tile buffers x {A0, A1, B0, B1} half-tiles of 16 KiB
+// (each half-tile is exactly the 128x64 / 64x128 swizzled image of gemm_common.h).  One workgroup per CU.
+//
+// A K-tile is consumed in 4 phases of 16 MFMAs per wave (one 64x32 output quadrant x K=64 each):
+//     ph1 (m0,n0): reads A(m0) 8 + B(n0) 4 fragments      ph2 (m0,n1): reads B(n1) 4
+//     ph3 (m1,n1): reads A(m1) 8                           ph4 (m1,n0): reads nothing
+// and every phase issues ONE half-tile of LDS-DMA (2 x global_load_lds_dwordx4 per wave) for a later K-tile:
+//     ph1(t): A0(t+1) -> buf^1   ph2(t): A1(t+1) -> buf^1   ph3(t): B0(t+2) -> buf   ph4(t): B1(t+2) -> buf
+// The B slots of the current buffer are dead after ph2, the A slots after ph3, which is what makes the re-staging
+// legal one barrier later (WAR); a single counted `s_waitcnt vmcnt(4)` per K-tile in ph4 (everything but the two
+// youngest half-tiles has landed) followed by that phase's barrier covers RAW for the next K-tile.  The loads are
+// never drained to zero inside the loop.  Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int HALF = 16384;            // bytes per half-tile
+constexpr int BUF = 4 * HALF;          // bytes per K-tile buffer
+
+struct Gemm256Args {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* R;
+    int M, N, K, lda, ldb, ldc, ldr;
+    long long sA, sB, sC, sR;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+// one 16-KiB half-tile by LDS-DMA: 16 pieces of 1 KiB over 8 waves
+template <int T>
+__device__ __forceinline__ void issue_half(const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0, char* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave * 2 + i;
+        const bf16_t* src;
+        if (T == 0) {
+            const int r = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            int gr = row0 + r;
+            gr = gr < rows ? gr : rows - 1;
+            src = P + (size_t)gr * ld + k0 + c * 8;
+        } else {
+            const int kr = 4 * j + (lane >> 4);
+            const int u = lane & 15;
+            const int sl = (u >> 1) ^ ks_swz(kr);
+            int gc = row0 + sl * 16 + (u & 1) * 8;
+            gc = gc < rows ? gc : rows - 8;
+            src = P + (size_t)(k0 + kr) * ld + gc;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
+    }
+}
+
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define BARRIER() __builtin_amdgcn_s_barrier()
+
+template <int TA, int TB, typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (id % per_group) % gsz;
+    const int tn = (id % per_group) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int bz = blockIdx.z;
+    const bf16_t* A = g.A + (size_t)bz * g.sA;
+    const bf16_t* B = g.B + (size_t)bz * g.sB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int a_half = wr;                 // which A half-tile this wave reads
+    const int b_half = wc >> 1;            // which B half-tile
+    const int b_off = (wc & 1) * 64;       // column offset of the wave inside its B half-tile
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / 64;
+    auto slot = [&](int b, int which) { return smem + b * BUF + which * HALF; };
+    auto issueA = [&](int h, int tile, int b) { issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slot(b, h)); };
+    auto issueB = [&](int h, int tile, int b) { issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slot(b, 2 + h)); };
+
+    // ---- prologue: tile 0 complete, B halves of tile 1 in flight
+    issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
+    if (nt > 1) { issueB(0, 1, 1); issueB(1, 1, 1); WAIT_VM(4); } else { WAIT_VM(0); }
+    BARRIER();
+
+    Frags<TA, 4> fa;
+    Frags<TB, 2> fb0, fb1;
+#define MFMA_QUAD(FB, MI, NJ)                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.get(j, ks), fa.get(i, ks), acc[MI + i][NJ + j], 0, 0, 0);
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        const char* la = slot(b, a_half);
+        const char* lb = slot(b, 2 + b_half);
+        // ---------------- phase 1: quadrant (m0, n0)
+        if (t + 1 < nt) issueA(0, t + 1, b ^ 1);
+        fb0.load(lb, b_off, lane);
+        fa.load(la, 0, lane);
+        frag_wait();
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(fb0, 0, 0)
+        __builtin_amdgcn_s_setprio(0);
+        BARRIER();
+        // ---------------- phase 2: quadrant (m0, n1)
+        if (t + 1 < nt) issueA(1, t + 1, b ^ 1);
+        fb1.load(lb, b_off + 32, lane);
+        frag_wait();
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(fb1, 0, 2)
+        __builtin_amdgcn_s_setprio(0);
+        BARRIER();
+        // ---------------- phase 3: quadrant (m1, n1)
+        if (t + 2 < nt) issueB(0, t + 2, b);
+        fa.load(la, 64, lane);
+        frag_wait();
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(fb1, 4, 2)
+        __builtin_amdgcn_s_setprio(0);
+        BARRIER();
+        // ---------------- phase 4: quadrant (m1, n0)
+        if (t + 2 < nt) issueB(1, t + 2, b);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(fb0, 4, 0)
+        __builtin_amdgcn_s_setprio(0);
+        if (t + 2 < nt) { WAIT_VM(4); } else { WAIT_VM(0); }   // tile t+1 has landed; at most B0/B1(t+2) in flight
+        BARRIER();
+    }
+#undef MFMA_QUAD
+
+    // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] of each 16x16 tile
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
+    const bf16_t* R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!R || (g.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + 16 * i + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + 16 * j + 4 * (lane >> 4);
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+            if (vec_ok && n + 3 < g.N) {
+                if (R) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + (size_t)m * g.ldr + n);
+                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                }
+                if constexpr (sizeof(OutT) == 2) {
+                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = o;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                for (int e = 0; e < 4 && n + e < g.N; ++e) {
+                    float x = v[e];
+                    if (R) x += bf2f(R[(size_t)m * g.ldr + n + e]);
+                    if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(C)[(size_t)m * g.ldc + n + e] = f2bf(x);
+                    else reinterpret_cast<float*>(C)[(size_t)m * g.ldc + n + e] = x;
+                }
+            }
+        }
+    }
+}
+
+template <int TA, int TB>
+int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) {
+    dim3 grid(g.tiles_m * g.tiles_n, 1, batch), block(512);
+    const size_t lds = 2 * BUF;
+    static bool attr_done[2] = {false, false};
+    if (out_f32) {
+        auto k = gemm256_kernel<TA, TB, float>;
+        if (!attr_done[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+        hipLaunchKernelGGL(k, grid, block, lds, stream, g);
+    } else {
+        auto k = gemm256_kernel<TA, TB, bf16_t>;
+        if (!attr_done[0]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+        hipLaunchKernelGGL(k, grid, block, lds, stream, g);
+    }
+    CSM_CHECK_LAUNCH("csm_gemm_bf16(256)");
+    return 0;
+}
+
+}  // namespace
+
+// called by csm_gemm_bf16 (gemm.hip) when the tile heuristic picks the 256x256 kernel; same argument meaning
+int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                       int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
+                       long long sC, long long sR, hipStream_t stream) {
+    Gemm256Args g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.sA = sA; g.sB = sB; g.sC = sC; g.sR = sR; g.alpha = alpha;
+    g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
+    if (!transA && !transB) return launch256<0, 0>(g, out_f32, batch, stream);
+    if (!transA && transB) return launch256<0, 1>(g, out_f32, batch, stream);
+    if (transA && transB) return launch256<1, 1>(g, out_f32, batch, stream);
+    return launch256<1, 0>(g, out_f32, batch, stream);
+}

@@ -1,0 +1,168 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (tile images, staging, fragment loads).  See gemm.hip for the scheme.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// XOR key of the k-strided ("ks") image: a 32-lane half of a transposed read touches k-rows {8g+q} and {8g+8+q}
+// (q = 0..3), so the key must separate rows that differ in bit 3 as well as in bits 0-1.
+__device__ __forceinline__ int ks_swz(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* R;
+    int M, N, K, lda, ldb, ldc, ldr;
+    long long sA, sB, sC, sR;  // batch strides in elements
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+// ---- staging: each thread moves 4 x 16 B per operand per K-tile --------------------------------
+template <int T>
+__device__ __forceinline__ void stage_load(const bf16_t* __restrict__ P, int ld, int rows /*M or N*/, int K,
+                                           int row0, int k0, U4 (&reg)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        U4 v = {0u, 0u, 0u, 0u};
+        if (T == 0) {
+            const int r = idx >> 3, c = idx & 7;
+            int gr = row0 + r;
+            gr = gr < rows ? gr : rows - 1;                 // clamp: garbage rows are masked at the store
+            const int gk = k0 + c * 8;
+            if (gk < K) v = *reinterpret_cast<const U4*>(P + (size_t)gr * ld + gk);
+        } else {
+            const int kr = idx >> 4, c = idx & 15;
+            const int gk = k0 + kr, gc = row0 + c * 8;
+            if (gk < K && gc < rows) v = *reinterpret_cast<const U4*>(P + (size_t)gk * ld + gc);
+        }
+        reg[i] = v;
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void stage_store(char* lds, const U4 (&reg)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        int off;
+        if (T == 0) {
+            const int r = idx >> 3, c = idx & 7;
+            off = r * 128 + ((c ^ (r & 7)) << 4);
+        } else {
+            const int kr = idx >> 4, c = idx & 15;
+            off = kr * 256 + ((((c >> 1) ^ ks_swz(kr)) << 5) | ((c & 1) << 4));
+        }
+        *reinterpret_cast<U4*>(lds + off) = reg[i];
+    }
+}
+
+// direct global->LDS staging (LDS-DMA, 16 B per lane, 1 KiB per wave-instruction).  The LDS destination is
+// wave-uniform base + lane*16, so the XOR swizzle is applied to the per-lane SOURCE address and the image is the
+// same one stage_store writes.  No zero fill: callers guarantee K % 64 == 0; row/column overhang is clamped.
+template <int T>
+__device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ P, int ld, int rows, int row0, int k0, char* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i;  // 1-KiB piece of the 16-KiB tile
+        const bf16_t* src;
+        if (T == 0) {
+            const int r = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            int gr = row0 + r;
+            gr = gr < rows ? gr : rows - 1;
+            src = P + (size_t)gr * ld + k0 + c * 8;
+        } else {
+            const int kr = 4 * j + (lane >> 4);
+            const int u = lane & 15;
+            const int sl = (u >> 1) ^ ks_swz(kr);
+            int gc = row0 + sl * 16 + (u & 1) * 8;
+            gc = gc < rows ? gc : rows - 8;
+            src = P + (size_t)(k0 + kr) * ld + gc;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
+    }
+}
+
+// ---- fragments ---------------------------------------------------------------------------------------------
+// Fragment of 16 tile-rows starting at r0 for k-step ks (32 deep): lane holds row (lane&15), k = 8*(lane>>4)+j.
+//
+// K-contiguous image (T == 0): one ds_read_b128, issued as a plain load (hipcc tracks its lgkmcnt).
+// K-strided image   (T == 1): two ds_read_b64_tr_b16, issued through INLINE ASM: hipcc treats the tr-read builtin
+//   as possibly aliasing an in-flight LDS-DMA and puts `s_waitcnt vmcnt(0)` in front of it, which drains the
+//   global_load_lds pipeline at every phase.  The asm form is invisible to that pass; in exchange the caller must
+//   run frag_wait() (s_waitcnt lgkmcnt(0) + sched_barrier) between the last read and the first MFMA, and only then
+//   assemble the two halves (cat4) so that any register copy happens after the data has landed.
+struct FragT1 { bf16x4 lo, hi; };
+
+__device__ __forceinline__ int tr_lane_off(int lane) {           // byte offset of (k-row 8g+q, column 4p) in slot 0
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    return (8 * g + q) * 256 + p * 8;
+}
+__device__ __forceinline__ int tr_lane_key(int lane) {           // ks_swz of every k-row this lane addresses
+    return ((lane >> 2) & 3) | (((lane >> 4) & 1) << 2);
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x4 tr_read_asm(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// addr = LDS byte address of the image + tr_lane_off + ((slot ^ key) << 5); KS selects the 32-deep k-step
+template <int KS>
+__device__ __forceinline__ FragT1 load_frag_tr(unsigned addr) {
+    FragT1 f;
+    f.lo = tr_read_asm<KS * 8192>(addr);
+    f.hi = tr_read_asm<KS * 8192 + 1024>(addr);
+    return f;
+}
+
+__device__ __forceinline__ bf16x8 load_frag_row(const char* lds, int r0, int ks, int lane) {
+    const int r = r0 + (lane & 15);
+    const int c = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((c ^ (r & 7)) << 4));
+}
+
+__device__ __forceinline__ void frag_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Operand fragments of NT 16-row tiles x 2 k-steps, for either image kind.
+template <int T, int NT>
+struct Frags {
+    bf16x8 row[NT][2];
+    FragT1 tr[NT][2];
+    // r0: first tile-row/column of tile 0 inside the image; tiles are 16 apart
+    __device__ __forceinline__ void load(const char* img, int r0, int lane) {
+        if constexpr (T == 0) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) row[i][ks] = load_frag_row(img, r0 + 16 * i, ks, lane);
+        } else {
+            const unsigned base = (unsigned)(uintptr_t)img + tr_lane_off(lane);
+            const int key = tr_lane_key(lane);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const unsigned a = base + ((((r0 >> 4) + i) ^ key) << 5);
+                tr[i][0] = load_frag_tr<0>(a);
+                tr[i][1] = load_frag_tr<1>(a);
+            }
+        }
+    }
+    __device__ __forceinline__ bf16x8 get(int i, int ks) const {
+        if constexpr (T == 0) return row[i][ks];
+        else return cat4(tr[i][ks].lo, tr[i][ks].hi);
+    }
+};
+
+}  // namespace

@@ -58,6 +58,57 @@ def test_gemm(dev, M, N, K, mode):
     close(f"gemm {mode} f32+R", C32, 0.5 * ref + R.float(), 2e-5 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (304, 520, 128), (1000, 2112, 1024), (264, 8, 192)])
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_256_tile_kernel(dev, M, N, K, mode):
+    """The deep-pipelined 256x256 kernel forced on (variant 3), including ragged edges and several K-tile counts
+    (1, 2, 3, 4, 16 tiles exercise prologue / steady state / tail of the LDS-DMA pipeline)."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(M + N * 3 + K * 7)
+    if mode == "nt":
+        A, B, tA, tB = rnd((M, K), g), rnd((N, K), g), False, False
+        ref = A.float() @ B.float().t()
+    elif mode == "nn":
+        A, B, tA, tB = rnd((M, K), g), rnd((K, N), g), False, True
+        ref = A.float() @ B.float()
+    else:
+        A, B, tA, tB = rnd((K, M), g), rnd((K, N), g), True, True
+        ref = A.float().t() @ B.float()
+    R = rnd((M, N), g)
+    ops.lib.csm_set_gemm_variant(3)
+    try:
+        C = torch.empty(M, N, dtype=BF, device=dev)
+        ops.gemm(A.to(dev), B.to(dev), C, None, tA, tB)
+        close(f"gemm256 {mode}", C, ref, 1e-2)
+        C32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        for _ in range(3):   # repeated launches: a staging race would show up as run-to-run differences
+            ops.gemm(A.to(dev), B.to(dev), C32, R.to(dev), tA, tB, alpha=0.5)
+            close(f"gemm256 {mode} f32+R", C32, 0.5 * ref + R.float(), 2e-5 * math.sqrt(K))
+    finally:
+        ops.lib.csm_set_gemm_variant(2)
+
+
+def test_gemm_256_bitwise_repeatable(dev):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(77)
+    A, B = rnd((2048, 2048), g).to(dev), rnd((2048, 2048), g).to(dev)
+    ops.lib.csm_set_gemm_variant(3)
+    try:
+        outs = []
+        for _ in range(4):
+            C = torch.empty(2048, 2048, dtype=torch.float32, device=dev)
+            ops.gemm(A, B, C, None, False, False)
+            outs.append(C)
+        ops.lib.csm_set_gemm_variant(1)
+        C1 = torch.empty(2048, 2048, dtype=torch.float32, device=dev)
+        ops.gemm(A, B, C1, None, False, False)
+    finally:
+        ops.lib.csm_set_gemm_variant(2)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert torch.equal(C1, outs[0]), "same k-order accumulation in both tile kernels"
+
+
 def test_gemm_asymmetric_identity(dev):
     """A = I with an asymmetric B catches a transposed C write (both operand orders)."""
     from csm.hip import ops
