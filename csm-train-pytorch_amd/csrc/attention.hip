@@ -91,21 +91,49 @@ __device__ __forceinline__ void load_rowfrags(const bf16_t* __restrict__ P, int 
         f[ks] = *reinterpret_cast<const bf16x8*>(P + (size_t)row * ld + ks * 32 + (lane >> 4) * 8);
 }
 
+// raw v_exp_f32 (no denormal-range fix-up: arguments here are <= ~0 and a flushed tiny result is exact enough)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max / sum across the four 16-lane rows of a wave with v_permlane16_swap + v_permlane32_swap (VALU, no LDS
+// round trip like __shfl_xor's ds_bpermute).  vdst = src = x: the swap leaves {even-row value, odd-row value} pairs.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));   // no canonicalising v_max in front
+    return r;
+}
+__device__ __forceinline__ float rows_max(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float a;
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(q[0])), "v"(__uint_as_float(q[1])));
+    return a;
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------
-// forward (BWD=false) and dQ (BWD=true) share one skeleton: block = 64 queries of one (b, h); wave = 16 queries.
-template <int HD, bool BWD>
-__global__ __launch_bounds__(256) void attn_q_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// forward (BWD=false) and dQ (BWD=true) share one skeleton: block = 64*QT queries of one (b, h); wave = QT tiles of
+// 16 queries, so every K / V fragment read from LDS feeds QT MFMAs.  K/V tiles are double-buffered in LDS
+// (global -> registers one key block ahead -> LDS after the compute), one barrier per key block.
+template <int HD, bool BWD, int QT>
+__global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, const bf16_t* __restrict__ dout,
                                                      const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                      int S, int H, int KV, float scale) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32;
+    constexpr int NIMG = BWD ? 3 : 2;
     using I = Img<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_row = smem;
-    char* v_img = smem + I::BYTES;          // fwd: V tr image;  bwd: V row image
-    char* k_tr = smem + 2 * I::BYTES;       // bwd only
+    auto k_row = [&](int st) { return smem + st * NIMG * I::BYTES; };
+    auto v_img = [&](int st) { return smem + st * NIMG * I::BYTES + I::BYTES; };      // fwd: V tr image; bwd: V row image
+    auto k_tr = [&](int st) { return smem + st * NIMG * I::BYTES + 2 * I::BYTES; };   // bwd only
 
     const int qb = gridDim.x - 1 - blockIdx.x;  // heaviest (most key blocks) first
     const int h = blockIdx.y, b = blockIdx.z;
@@ -114,116 +142,171 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16_t* __restrict__ 
     const bf16_t* Qp = qkv + (size_t)b * S * ld + h * HD;
     const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * HD;
     const bf16_t* Vp = qkv + (size_t)b * S * ld + (H + KV + kvh) * HD;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int qrow = qb * 64 + wave * 16 + (lane & 15);
-    const int qrow_c = qrow < S ? qrow : S - 1;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q_base = qb * 64 * QT;
     const float c2 = scale * 1.4426950408889634f;
 
-    bf16x8 qf[NKS], dof[NKS];
-    load_rowfrags<HD>(Qp, ld, qrow_c, qf, lane);
-    float my_lse = 0.f, my_delta = 0.f;
-    if (BWD) {
-        load_rowfrags<HD>(dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qrow_c, dof, lane);
-        my_lse = lse[((size_t)b * H + h) * S + qrow_c] * 1.4426950408889634f;
-        my_delta = delta[((size_t)b * H + h) * S + qrow_c];
+    int r0[QT], qrow[QT];
+    bf16x8 qf[QT][NKS], dof[QT][NKS];
+    float nlse2[QT], my_delta[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        r0[qt] = q_base + (wave * QT + qt) * 16;
+        qrow[qt] = r0[qt] + (lane & 15);
+        const int qc = qrow[qt] < S ? qrow[qt] : S - 1;
+        load_rowfrags<HD>(Qp, ld, qc, qf[qt], lane);
+        if (BWD) {
+            load_rowfrags<HD>(dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qc, dof[qt], lane);
+            nlse2[qt] = -lse[((size_t)b * H + h) * S + qc] * 1.4426950408889634f;
+            my_delta[qt] = delta[((size_t)b * H + h) * S + qc];
+        }
     }
 
-    f32x4 o[NDT];
+    f32x4 o[QT][NDT];
+    float m[QT], l[QT];
 #pragma unroll
-    for (int i = 0; i < NDT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    for (int qt = 0; qt < QT; ++qt) {
+        m[qt] = -INFINITY; l[qt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) o[qt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
+    int last = q_base + 64 * QT - 1;
+    last = last < S ? last : S - 1;
+    const int nkb = last / 64 + 1;
     U4 kreg[NST], vreg[NST];
     tile_load<HD>(Kp, ld, S, 0, kreg);
     tile_load<HD>(Vp, ld, S, 0, vreg);
+    tile_store<HD, true, BWD>(k_row(0), k_tr(0), kreg);
+    tile_store<HD, BWD, !BWD>(v_img(0), v_img(0), vreg);
+    __syncthreads();
 
-    for (int kb = 0; kb <= qb; ++kb) {
-        __syncthreads();
-        tile_store<HD, true, BWD>(k_row, k_tr, kreg);
-        tile_store<HD, BWD, !BWD>(v_img, v_img, vreg);
-        __syncthreads();
-        if (kb < qb) {
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int st = kb & 1;
+        if (kb + 1 < nkb) {
             tile_load<HD>(Kp, ld, S, (kb + 1) * 64, kreg);
             tile_load<HD>(Vp, ld, S, (kb + 1) * 64, vreg);
         }
-        f32x4 s[4], dp[4];
+        const int key0 = kb * 64;
+        bool active[QT];
+        bool any = false;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < QT; ++qt) { active[qt] = key0 <= r0[qt] + 15; any |= active[qt]; }
+        if (any) {
+            f32x4 s[QT][4], dp[QT][4];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) s[kt] = MFMA(frag_row<HD>(k_row, 16 * kt, ks, lane), qf[ks], s[kt]);
-            if (BWD) {
-                dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < 4; ++kt) {
+                bf16x8 kfr[NKS], vfr[NKS];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) dp[kt] = MFMA(frag_row<HD>(v_img, 16 * kt, ks, lane), dof[ks], dp[kt]);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    kfr[ks] = frag_row<HD>(k_row(st), 16 * kt, ks, lane);
+                    if (BWD) vfr[ks] = frag_row<HD>(v_img(st), 16 * kt, ks, lane);
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (BWD) dp[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (active[qt]) {
+#pragma unroll
+                        for (int ks = 0; ks < NKS; ++ks) {
+                            s[qt][kt] = MFMA(kfr[ks], qf[qt][ks], s[qt][kt]);
+                            if (BWD) dp[qt][kt] = MFMA(vfr[ks], dof[qt][ks], dp[qt][kt]);
+                        }
+                    }
+                }
             }
-        }
-        // s[kt][r] = S[key = kb*64 + 16kt + 4g + r][q = qrow]
-        if (kb == qb) {
+            bf16x8 pf[QT][2];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kb * 64 + 16 * kt + 4 * g + r > qrow) s[kt][r] = -INFINITY;
-        }
-        if (!BWD) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);
-            const float alpha = exp2f((m - m_new) * c2);
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f((s[kt][r] - m_new) * c2);
-                    s[kt][r] = p;
-                    sum += p;
+            for (int qt = 0; qt < QT; ++qt) {
+                if (!active[qt]) {
+                    pf[qt][0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    pf[qt][1] = pf[qt][0];
+                    continue;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            l = l * alpha + sum;
-            m = m_new;
+                // s[qt][kt][r] = S[key = key0 + 16kt + 4g + r][q = qrow[qt]]
+                if (key0 + 63 > r0[qt]) {
 #pragma unroll
-            for (int i = 0; i < NDT; ++i) o[i] *= alpha;
-        } else {
+                    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                        for (int r = 0; r < 4; ++r)
+                            if (key0 + 16 * kt + 4 * g + r > qrow[qt]) s[qt][kt][r] = -INFINITY;
+                }
+                if (!BWD) {
+                    float mx = max3(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
+                    mx = max3(mx, s[qt][0][3], s[qt][1][0]);
+                    mx = max3(mx, s[qt][1][1], s[qt][1][2]);
+                    mx = max3(mx, s[qt][1][3], s[qt][2][0]);
+                    mx = max3(mx, s[qt][2][1], s[qt][2][2]);
+                    mx = max3(mx, s[qt][2][3], s[qt][3][0]);
+                    mx = max3(mx, s[qt][3][1], s[qt][3][2]);
+                    mx = rows_max(max3(mx, s[qt][3][3], m[qt]));     // running max folded in
+                    const float m_new = mx;
+                    if (!__all(m_new == m[qt])) {          // wave-uniform: rescale only when some row's max moved
+                        const float alpha = fast_exp2((m[qt] - m_new) * c2);
+                        l[qt] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[kt][r] * c2 - my_lse);   // masked: exp2(-inf) = 0
-                    s[kt][r] = p * (dp[kt][r] - my_delta) * scale;   // dS^T
+                        for (int i = 0; i < NDT; ++i) o[qt][i] *= alpha;
+                        m[qt] = m_new;
+                    }
+                    const float nb = -m_new * c2;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = fast_exp2(fmaf(s[qt][kt][r], c2, nb));
+                            s[qt][kt][r] = p;
+                            sum += p;
+                        }
+                    l[qt] += rows_sum(sum);
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = fast_exp2(fmaf(s[qt][kt][r], c2, nlse2[qt]));   // masked: exp2(-inf) = 0
+                            s[qt][kt][r] = p * (dp[qt][kt][r] - my_delta[qt]) * scale;  // dS^T
+                        }
+                }
+                pf[qt][0] = frag_from_acc(s[qt][0], s[qt][1]);
+                pf[qt][1] = frag_from_acc(s[qt][2], s[qt][3]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const bf16x8 vt = frag_tr<HD>(BWD ? k_tr(st) : v_img(st), dt, s2, lane);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        if (active[qt]) o[qt][dt] = MFMA(vt, pf[qt][s2], o[qt][dt]);
                 }
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = frag_from_acc(s[2 * s2], s[2 * s2 + 1]);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt] = MFMA(frag_tr<HD>(BWD ? k_tr : v_img, dt, s2, lane), pf, o[dt]);
+        if (kb + 1 < nkb) {
+            tile_store<HD, true, BWD>(k_row(st ^ 1), k_tr(st ^ 1), kreg);
+            tile_store<HD, BWD, !BWD>(v_img(st ^ 1), v_img(st ^ 1), vreg);
         }
+        __syncthreads();
     }
 
-    // o[dt][r] = O^T (or dQ^T) [d = 16dt + 4g + r][q = qrow]
-    if (qrow < S) {
+    // o[qt][dt][r] = O^T (or dQ^T) [d = 16dt + 4g + r][q = qrow[qt]]
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        if (qrow[qt] >= S) continue;
         if (!BWD) {
-            const float inv = 1.f / l;
-            bf16_t* op = out + ((size_t)b * S + qrow) * (H * HD) + h * HD;
+            const float inv = 1.f / l[qt];
+            bf16_t* op = out + ((size_t)b * S + qrow[qt]) * (H * HD) + h * HD;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                uint2 w; w.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+                uint2 w; w.x = pack2bf(o[qt][dt][0] * inv, o[qt][dt][1] * inv); w.y = pack2bf(o[qt][dt][2] * inv, o[qt][dt][3] * inv);
                 *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
             }
-            if (g == 0) lse[((size_t)b * H + h) * S + qrow] = m * scale + logf(l);
+            if (g == 0) lse[((size_t)b * H + h) * S + qrow[qt]] = m[qt] * scale + logf(l[qt]);
         } else {
-            bf16_t* op = dqkv + ((size_t)b * S + qrow) * ld + h * HD;
+            bf16_t* op = dqkv + ((size_t)b * S + qrow[qt]) * ld + h * HD;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                uint2 w; w.x = pack2bf(o[dt][0], o[dt][1]); w.y = pack2bf(o[dt][2], o[dt][3]);
+                uint2 w; w.x = pack2bf(o[qt][dt][0], o[qt][dt][1]); w.y = pack2bf(o[qt][dt][2], o[qt][dt][3]);
                 *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
             }
         }
@@ -231,33 +314,38 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// dK / dV: block = 64*KT keys of one (b, kv-head); wave = KT tiles of 16 keys; loops q-heads of the group and
-// q-blocks at or below the diagonal.
+// dK / dV: block = 64*KT keys of one (b, kv-head); wave = KT tiles of 16 keys; loops the q-heads of the group and the
+// q-blocks at or below the diagonal.  Q / dO tiles (row + transposed images) and the block's lse / delta are
+// double-buffered in LDS; one barrier per q-block.
 template <int HD, int KT>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                       const float* __restrict__ lse, const float* __restrict__ delta,
-                                                       bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32, KB = 64 * KT;
     using I = Img<HD>;
+    constexpr int STAGE = 4 * I::BYTES + 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* q_row = smem;
-    char* q_tr = smem + I::BYTES;
-    char* do_row = smem + 2 * I::BYTES;
-    char* do_tr = smem + 3 * I::BYTES;
+    auto q_row = [&](int st) { return smem + st * STAGE; };
+    auto q_tr = [&](int st) { return smem + st * STAGE + I::BYTES; };
+    auto do_row = [&](int st) { return smem + st * STAGE + 2 * I::BYTES; };
+    auto do_tr = [&](int st) { return smem + st * STAGE + 3 * I::BYTES; };
+    auto stat = [&](int st) { return reinterpret_cast<float*>(smem + st * STAGE + 4 * I::BYTES); };  // [0..63] lse*log2e, [64..127] delta
 
     const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
     const int rep = H / KV;
     const int ld = (H + 2 * KV) * HD, ldo = H * HD;
     const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * HD;
     const bf16_t* Vp = qkv + (size_t)b * S * ld + (H + KV + kvh) * HD;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float c2 = scale * 1.4426950408889634f;
 
     bf16x8 kf[KT][NKS], vf[KT][NKS];
-    int key[KT];
+    int key[KT], key0[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        key[t] = kblk * KB + (wave * KT + t) * 16 + (lane & 15);
+        key0[t] = kblk * KB + (wave * KT + t) * 16;
+        key[t] = key0[t] + (lane & 15);
         const int kc = key[t] < S ? key[t] : S - 1;
         load_rowfrags<HD>(Kp, ld, kc, kf[t], lane);
         load_rowfrags<HD>(Vp, ld, kc, vf[t], lane);
@@ -270,68 +358,96 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const bf16_t* __restrict_
 
     const int nqb = (S + 63) / 64;
     const int qb0 = (kblk * KB) / 64;
-    const int niter = rep * (nqb - qb0);
+    const int per_head = nqb - qb0;
+    const int niter = rep * per_head;
     U4 qreg[NST], dreg[NST];
-    if (niter > 0) {
-        tile_load<HD>(qkv + (size_t)b * S * ld + (kvh * rep) * HD, ld, S, qb0 * 64, qreg);
-        tile_load<HD>(dout + (size_t)b * S * ldo + (kvh * rep) * HD, ldo, S, qb0 * 64, dreg);
-    }
-    for (int it = 0; it < niter; ++it) {
-        const int hh = it / (nqb - qb0), qb = qb0 + it % (nqb - qb0);
+    float streg = 0.f;
+    auto prefetch = [&](int it) {
+        const int hh = it / per_head, qb = qb0 + it % per_head;
         const int h = kvh * rep + hh;
-        __syncthreads();
-        tile_store<HD, true, true>(q_row, q_tr, qreg);
-        tile_store<HD, true, true>(do_row, do_tr, dreg);
-        __syncthreads();
-        if (it + 1 < niter) {
-            const int hh1 = (it + 1) / (nqb - qb0), qb1 = qb0 + (it + 1) % (nqb - qb0);
-            tile_load<HD>(qkv + (size_t)b * S * ld + (kvh * rep + hh1) * HD, ld, S, qb1 * 64, qreg);
-            tile_load<HD>(dout + (size_t)b * S * ldo + (kvh * rep + hh1) * HD, ldo, S, qb1 * 64, dreg);
+        tile_load<HD>(qkv + (size_t)b * S * ld + h * HD, ld, S, qb * 64, qreg);
+        tile_load<HD>(dout + (size_t)b * S * ldo + h * HD, ldo, S, qb * 64, dreg);
+        if (threadIdx.x < 128) {
+            int q = qb * 64 + (threadIdx.x & 63);
+            q = q < S ? q : S - 1;
+            const size_t idx = ((size_t)b * H + h) * S + q;
+            streg = threadIdx.x < 64 ? lse[idx] * 1.4426950408889634f : delta[idx];
         }
-        // per-register row constants: q = qb*64 + 16qt + 4g + r
-        float lse4[4][4], del4[4][4];
+    };
+    auto commit = [&](int st) {
+        tile_store<HD, true, true>(q_row(st), q_tr(st), qreg);
+        tile_store<HD, true, true>(do_row(st), do_tr(st), dreg);
+        if (threadIdx.x < 128) stat(st)[threadIdx.x] = streg;
+    };
+    if (niter > 0) { prefetch(0); commit(0); }
+    __syncthreads();
+
+    for (int it = 0; it < niter; ++it) {
+        const int st = it & 1;
+        const int qb = qb0 + it % per_head;
+        if (it + 1 < niter) prefetch(it + 1);
+        bool active[KT];
+        bool any = false;
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = qb * 64 + 16 * qt + 4 * g + r;
-                const int qc = q < S ? q : S - 1;
-                lse4[qt][r] = lse[((size_t)b * H + h) * S + qc] * 1.4426950408889634f;
-                del4[qt][r] = delta[((size_t)b * H + h) * S + qc];
-            }
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            f32x4 s[4], dp[4];
+        for (int t = 0; t < KT; ++t) { active[t] = key0[t] <= qb * 64 + 63; any |= active[t]; }
+        if (any) {
+            f32x4 s[KT][4], dp[KT][4];
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
-                s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float4 l4 = *reinterpret_cast<const float4*>(stat(st) + 16 * qt + 4 * g);
+                const float4 d4 = *reinterpret_cast<const float4*>(stat(st) + 64 + 16 * qt + 4 * g);
+                const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
+                bf16x8 qfr[NKS], dofr[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    s[qt] = MFMA(frag_row<HD>(q_row, 16 * qt, ks, lane), kf[t][ks], s[qt]);
-                    dp[qt] = MFMA(frag_row<HD>(do_row, 16 * qt, ks, lane), vf[t][ks], dp[qt]);
+                    qfr[ks] = frag_row<HD>(q_row(st), 16 * qt, ks, lane);
+                    dofr[ks] = frag_row<HD>(do_row(st), 16 * qt, ks, lane);
                 }
-                // s[qt][r] = S[q = qb*64+16qt+4g+r][key = key[t]]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = qb * 64 + 16 * qt + 4 * g + r;
-                    float p = exp2f(s[qt][r] * c2 - lse4[qt][r]);
-                    if (key[t] > q || q >= S) p = 0.f;
-                    s[qt][r] = p;
-                    dp[qt][r] = p * (dp[qt][r] - del4[qt][r]) * scale;
+                for (int t = 0; t < KT; ++t) {
+                    s[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    dp[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (!active[t]) continue;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s[t][qt] = MFMA(qfr[ks], kf[t][ks], s[t][qt]);
+                        dp[t][qt] = MFMA(dofr[ks], vf[t][ks], dp[t][qt]);
+                    }
+                    // s[t][qt][r] = S[q = qb*64+16qt+4g+r][key = key[t]]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = qb * 64 + 16 * qt + 4 * g + r;
+                        float p = fast_exp2(fmaf(s[t][qt][r], c2, -lse4[r]));
+                        if (key[t] > q || q >= S) p = 0.f;
+                        s[t][qt][r] = p;
+                        dp[t][qt][r] = p * (dp[t][qt][r] - del4[r]) * scale;
+                    }
                 }
             }
+            bf16x8 pf[KT][2], dsf[KT][2];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = frag_from_acc(s[2 * s2], s[2 * s2 + 1]);
-                const bf16x8 dsf = frag_from_acc(dp[2 * s2], dp[2 * s2 + 1]);
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    pf[t][s2] = frag_from_acc(s[t][2 * s2], s[t][2 * s2 + 1]);
+                    dsf[t][s2] = frag_from_acc(dp[t][2 * s2], dp[t][2 * s2 + 1]);
+                }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    dv[t][dt] = MFMA(frag_tr<HD>(do_tr, dt, s2, lane), pf, dv[t][dt]);
-                    dk[t][dt] = MFMA(frag_tr<HD>(q_tr, dt, s2, lane), dsf, dk[t][dt]);
+                    const bf16x8 dot = frag_tr<HD>(do_tr(st), dt, s2, lane);
+                    const bf16x8 qtt = frag_tr<HD>(q_tr(st), dt, s2, lane);
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {
+                        if (!active[t]) continue;
+                        dv[t][dt] = MFMA(dot, pf[t][s2], dv[t][dt]);
+                        dk[t][dt] = MFMA(qtt, dsf[t][s2], dk[t][dt]);
+                    }
                 }
-            }
         }
+        if (it + 1 < niter) commit(st ^ 1);
+        __syncthreads();
     }
     // dk[t][dt][r] = dK^T[d = 16dt + 4g + r][key = key[t]]
 #pragma unroll
@@ -386,18 +502,49 @@ static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
     return 0;
 }
 
+template <int HD, bool BWD, int QT>
+static void launch_q(const void* qkv, void* out, float* lse, const void* dout, const float* delta, void* dqkv, int B, int S,
+                     int H, int KV, float scale, hipStream_t stream) {
+    constexpr int lds = 2 * (BWD ? 3 : 2) * Img<HD>::BYTES;
+    auto k = attn_q_kernel<HD, BWD, QT>;
+    static bool done = false;
+    if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+    done = true;
+    dim3 grid((S + 64 * QT - 1) / (64 * QT), H, B), block(256);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (const bf16_t*)dout, delta,
+                       (bf16_t*)dqkv, S, H, KV, scale);
+}
+
+template <int HD, int KT>
+static void launch_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
+                       int KV, float scale, hipStream_t stream) {
+    constexpr int lds = 2 * (4 * Img<HD>::BYTES + 512);
+    auto k = attn_dkv_kernel<HD, KT>;
+    static bool done = false;
+    if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+    done = true;
+    dim3 grid((S + 64 * KT - 1) / (64 * KT), KV, B), block(256);
+    hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, S, H, KV,
+                       scale);
+}
+
+static int g_attn_qt = 1;   // query tiles per wave for the head_dim-64 forward / dQ kernels (tuning switch)
+extern "C" int csm_set_attn_variant(int qt) {
+    g_attn_qt = qt;
+    return 0;
+}
+
 extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, int HD,
                             hipStream_t stream) {
     if (int e = check_attn("csm_attn_fwd", B, S, H, KV, HD)) return e;
     CSM_REQUIRE(qkv && out && lse, "csm_attn_fwd: null pointer");
-    dim3 grid((S + 63) / 64, H, B), block(256);
     const float scale = 1.f / sqrtf((float)HD);
-    if (HD == 64)
-        hipLaunchKernelGGL((attn_q_kernel<64, false>), grid, block, 2 * Img<64>::BYTES, stream, (const bf16_t*)qkv,
-                           (bf16_t*)out, lse, nullptr, nullptr, nullptr, S, H, KV, scale);
-    else
-        hipLaunchKernelGGL((attn_q_kernel<128, false>), grid, block, 2 * Img<128>::BYTES, stream, (const bf16_t*)qkv,
-                           (bf16_t*)out, lse, nullptr, nullptr, nullptr, S, H, KV, scale);
+    if (HD == 64) {
+        if (S > 64 && g_attn_qt == 2) launch_q<64, false, 2>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
+        else launch_q<64, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
+    } else {
+        launch_q<128, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
+    }
     CSM_CHECK_LAUNCH("csm_attn_fwd");
     return 0;
 }
@@ -414,21 +561,15 @@ extern "C" int csm_attn_bwd(const void* qkv, const void* out, const void* dout, 
                            (const bf16_t*)out, (const bf16_t*)dout, delta_ws, B, S, H, HD);
         CSM_CHECK_LAUNCH("csm_attn_bwd(delta)");
     }
-    dim3 block(256);
     if (HD == 64) {
-        hipLaunchKernelGGL((attn_dkv_kernel<64, 2>), dim3((S + 127) / 128, KV, B), block, 4 * Img<64>::BYTES, stream,
-                           (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, S, H, KV, scale);
+        launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
-        hipLaunchKernelGGL((attn_q_kernel<64, true>), dim3((S + 63) / 64, H, B), block, 3 * Img<64>::BYTES, stream,
-                           (const bf16_t*)qkv, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta_ws,
-                           (bf16_t*)dqkv, S, H, KV, scale);
+        if (S > 64 && g_attn_qt == 2) launch_q<64, true, 2>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        else launch_q<64, true, 1>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
     } else {
-        hipLaunchKernelGGL((attn_dkv_kernel<128, 1>), dim3((S + 63) / 64, KV, B), block, 4 * Img<128>::BYTES, stream,
-                           (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, S, H, KV, scale);
+        launch_dkv<128, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
-        hipLaunchKernelGGL((attn_q_kernel<128, true>), dim3((S + 63) / 64, H, B), block, 3 * Img<128>::BYTES, stream,
-                           (const bf16_t*)qkv, nullptr, const_cast<float*>(lse), (const bf16_t*)dout, delta_ws,
-                           (bf16_t*)dqkv, S, H, KV, scale);
+        launch_q<128, true, 1>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
     }
     CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
     return 0;

@@ -131,15 +131,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
 }
 
-// dst(bf16)[col] (+)= sum_r partials[r][col]
+// dst(bf16)[col] (+)= sum_r partials[r][col]; block = 64 columns x 4 row slices (coalesced 256-B row reads)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int rows, int D, bf16_t* __restrict__ dst,
                                                      int accumulate) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= D) return;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
     float t = 0.f;
-    for (int r = 0; r < rows; ++r) t += partials[(size_t)r * D + col];
-    if (accumulate) t += bf2f(dst[col]);
-    dst[col] = f2bf(t);
+    if (col < D)
+        for (int r = sl; r < rows; r += 4) t += partials[(size_t)r * D + col];
+    red[sl][c] = t;
+    __syncthreads();
+    if (sl == 0 && col < D) {
+        t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        if (accumulate) t += bf2f(dst[col]);
+        dst[col] = f2bf(t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ RoPE
@@ -469,7 +476,7 @@ extern "C" int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rs
 
 extern "C" int csm_colsum_bf16(const float* partials, int rows, int D, void* dst, int accumulate, hipStream_t stream) {
     CSM_REQUIRE(partials && dst && rows > 0 && D > 0, "csm_colsum_bf16: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, partials, rows, D, (bf16_t*)dst, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, rows, D, (bf16_t*)dst, accumulate);
     CSM_CHECK_LAUNCH("csm_colsum_bf16");
     return 0;
 }
