@@ -186,8 +186,12 @@ static bool prefer_256(int M, int N, int K, int batch) {
 }
 
 // tuning / A-B switch used by tools/gemm_bench.py: 0 register staging, 1 LDS-DMA 128x128, 2 auto (default), 3 force 256x256
+void csm_gemm256_set_pipelined(int v);
+// 0 register staging, 1 LDS-DMA 128x128, 2 auto (default), 3 force 256x256 (4-quadrant phases), 4 force 256x256 with
+// register-pipelined phases, 5 auto with the 4-quadrant 256 kernel
 extern "C" int csm_set_gemm_variant(int v) {
-    g_gemm_variant = v;
+    csm_gemm256_set_pipelined(v == 3 || v == 5 ? 0 : 1);
+    g_gemm_variant = (v == 4) ? 3 : (v == 5 ? 2 : v);
     return 0;
 }
 

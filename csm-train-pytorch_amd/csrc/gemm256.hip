@@ -185,12 +185,162 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant with register-level software pipelining: a phase multiplies ONE pair of A m-tiles (32 rows) by all four B
+// n-tiles of the wave (16 MFMAs) while the NEXT pair's fragments are already being read from LDS into the other A
+// register set, so fragment reads run under the MFMAs instead of in front of them.  Only the 8 B fragment reads at
+// the start of a K-tile are exposed.  Slot liveness: B slots of the current buffer are dead after ph1, A slots after
+// ph3 (ph3 drains its prefetch reads before the barrier), giving the DMA order
+//     ph1(t): A1(t+1) -> buf^1    ph2(t): B0(t+2) -> buf    ph3(t): B1(t+2) -> buf    ph4(t): A0(t+2) -> buf
+// and one counted wait per K-tile at the end of ph3 (vmcnt(4): everything up to A1(t+1) has landed).
+template <int TA, int TB, typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (id % per_group) % gsz;
+    const int tn = (id % per_group) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int bz = blockIdx.z;
+    const bf16_t* A = g.A + (size_t)bz * g.sA;
+    const bf16_t* B = g.B + (size_t)bz * g.sB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int a_half = wr, b_half = wc >> 1, b_off = (wc & 1) * 64;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / 64;
+    // LDS map (160 KiB): A double-buffered [2][2 halves] at 0..64 KiB, B TRIPLE-buffered [3][2 halves] at 64..160 KiB
+    auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
+    auto slotB = [&](int b3, int h) { return smem + 4 * HALF + b3 * (2 * HALF) + h * HALF; };
+    auto issueA = [&](int h, int tile, int b) { issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slotA(b, h)); };
+    auto issueB = [&](int h, int tile, int b3) { issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slotB(b3, h)); };
+    constexpr int NRA = (TA == 0) ? 4 : 8;     // LDS read instructions per prefetched A pair
+
+    issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
+    if (nt > 1) { issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1); WAIT_VM(6); } else { WAIT_VM(0); }
+    BARRIER();
+
+    Frags<TB, 4> fb;
+    Frags<TA, 2> fa0, fa1;
+    fa0.load(slotA(0, a_half), 0, lane);
+    int b3 = 0;   // t % 3
+#define WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MFMA_PAIR(FA, MI)                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                acc[MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), FA.get(i, ks), acc[MI + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        const int b3n = b3 == 0 ? 2 : b3 - 1;            // (t + 2) % 3
+        const char* la = slotA(b, a_half);
+        const char* lb = slotB(b3, b_half);
+        // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
+        if (t + 1 < nt) issueA(1, t + 1, b ^ 1);
+        fb.load(lb, b_off, lane);
+        fa1.load(la, 32, lane);
+        WAIT_LGKM(NRA);
+        MFMA_PAIR(fa0, 0)
+        // ---- ph2: pair 1 (set 1)   | prefetch pair 2 -> set 0
+        if (t + 2 < nt) issueB(0, t + 2, b3n);
+        fa0.load(la, 64, lane);
+        WAIT_LGKM(NRA);
+        MFMA_PAIR(fa1, 2)
+        // (no barrier: the B slots were released by ph1's barrier, nothing new has to be visible yet)
+        // ---- ph3: pair 2 (set 0)   | prefetch pair 3 -> set 1
+        if (t + 2 < nt) issueB(1, t + 2, b3n);
+        fa1.load(la, 96, lane);
+        WAIT_LGKM(NRA);
+        MFMA_PAIR(fa0, 4)
+        WAIT_LGKM(0);                                           // pair-3 reads done: the A slots of this buffer are dead
+        if (t + 2 < nt) { WAIT_VM(4); } else { WAIT_VM(0); }    // tile t+1 has landed
+        BARRIER();
+        // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
+        if (t + 2 < nt) issueA(0, t + 2, b);
+        if (t + 1 < nt) fa0.load(slotA(b ^ 1, a_half), 0, lane);
+        WAIT_LGKM(NRA);
+        MFMA_PAIR(fa1, 6)
+        // (no barrier: ph1(t+1) only touches slots ph3's barrier has already released / published)
+        b3 = b3 == 2 ? 0 : b3 + 1;
+    }
+#undef MFMA_PAIR
+
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
+    const bf16_t* R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!R || (g.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + 16 * i + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + 16 * j + 4 * (lane >> 4);
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+            if (vec_ok && n + 3 < g.N) {
+                if (R) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + (size_t)m * g.ldr + n);
+                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                }
+                if constexpr (sizeof(OutT) == 2) {
+                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = o;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                for (int e = 0; e < 4 && n + e < g.N; ++e) {
+                    float x = v[e];
+                    if (R) x += bf2f(R[(size_t)m * g.ldr + n + e]);
+                    if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(C)[(size_t)m * g.ldc + n + e] = f2bf(x);
+                    else reinterpret_cast<float*>(C)[(size_t)m * g.ldc + n + e] = x;
+                }
+            }
+        }
+    }
+}
+
+int g_gemm256_pipelined = 1;
+
 template <int TA, int TB>
 int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) {
     dim3 grid(g.tiles_m * g.tiles_n, 1, batch), block(512);
     const size_t lds = 2 * BUF;
     static bool attr_done[2] = {false, false};
-    if (out_f32) {
+    if (g_gemm256_pipelined) {
+        const size_t lds = 10 * HALF;   // 160 KiB
+        static bool pdone[2] = {false, false};
+        if (out_f32) {
+            auto k = gemm256p_kernel<TA, TB, float>;
+            if (!pdone[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); pdone[1] = true; }
+            hipLaunchKernelGGL(k, grid, block, lds, stream, g);
+        } else {
+            auto k = gemm256p_kernel<TA, TB, bf16_t>;
+            if (!pdone[0]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); pdone[0] = true; }
+            hipLaunchKernelGGL(k, grid, block, lds, stream, g);
+        }
+    } else if (out_f32) {
         auto k = gemm256_kernel<TA, TB, float>;
         if (!attr_done[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
         hipLaunchKernelGGL(k, grid, block, lds, stream, g);
@@ -204,6 +354,8 @@ int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) 
 }
 
 }  // namespace
+
+void csm_gemm256_set_pipelined(int v) { g_gemm256_pipelined = v; }
 
 // called by csm_gemm_bf16 (gemm.hip) when the tile heuristic picks the 256x256 kernel; same argument meaning
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,

@@ -60,7 +60,8 @@ def test_gemm(dev, M, N, K, mode):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (304, 520, 128), (1000, 2112, 1024), (264, 8, 192)])
 @pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
-def test_gemm_256_tile_kernel(dev, M, N, K, mode):
+@pytest.mark.parametrize("variant", [3, 4])
+def test_gemm_256_tile_kernel(dev, M, N, K, mode, variant):
     """The deep-pipelined 256x256 kernel forced on (variant 3), including ragged edges and several K-tile counts
     (1, 2, 3, 4, 16 tiles exercise prologue / steady state / tail of the LDS-DMA pipeline)."""
     from csm.hip import ops
@@ -75,7 +76,7 @@ def test_gemm_256_tile_kernel(dev, M, N, K, mode):
         A, B, tA, tB = rnd((K, M), g), rnd((K, N), g), True, True
         ref = A.float().t() @ B.float()
     R = rnd((M, N), g)
-    ops.lib.csm_set_gemm_variant(3)
+    ops.lib.csm_set_gemm_variant(variant)
     try:
         C = torch.empty(M, N, dtype=BF, device=dev)
         ops.gemm(A.to(dev), B.to(dev), C, None, tA, tB)
@@ -92,10 +93,10 @@ def test_gemm_256_bitwise_repeatable(dev):
     from csm.hip import ops
     g = torch.Generator().manual_seed(77)
     A, B = rnd((2048, 2048), g).to(dev), rnd((2048, 2048), g).to(dev)
-    ops.lib.csm_set_gemm_variant(3)
     try:
         outs = []
-        for _ in range(4):
+        for v in (3, 4, 3, 4):
+            ops.lib.csm_set_gemm_variant(v)
             C = torch.empty(2048, 2048, dtype=torch.float32, device=dev)
             ops.gemm(A, B, C, None, False, False)
             outs.append(C)
