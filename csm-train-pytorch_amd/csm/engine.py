@@ -281,12 +281,8 @@ class Engine:
         train_embeddings, train_other = tr["embeddings"], tr["other"]
         m.ensure_grads()
         hidden = s["hidden"]
-        dhid_f32 = None
-        d_text = d_audio = None
-        if train_embeddings:
-            d_text = torch.zeros(m.block("text_embeddings.weight").shape, dtype=F32, device=dev)
-            d_audio = torch.zeros(m.block("audio_embeddings.weight").shape, dtype=F32, device=dev)
-
+        dseq = None
+        dec_pos0 = None
         # ---- depth decoder (acoustic term)
         dec = s["dec"]
         if dec is not None and s["aw"] != 0.0:
@@ -308,8 +304,7 @@ class Engine:
             ops.linear_dx(dx0, m.block("projection.weight"), dseq)
             if train_other:
                 ops.linear_dw(dx0, dec["seq"], m.block("projection.weight", True), accumulate=True)
-            dhid_f32 = torch.zeros(M, d, dtype=F32, device=dev)
-            ops.decoder_input_bwd(dseq, dec["rows"], dec["codes"], dhid_f32, d_audio, V)
+            dec_pos0 = (dseq, dec["rows"], K)          # position 0 of every frame is the backbone state: scattered below
             if self.grad_hook is not None:
                 self.grad_hook("decoder", -1)
 
@@ -322,19 +317,43 @@ class Engine:
         if train_other:
             ops.linear_dw(dlog, hidden, m.block("codebook0_head.padded", True), accumulate=True)
         del dlog
-        if dhid_f32 is not None:
-            ops.add_f32_into_bf16(dhid, dhid_f32)
+        if dec_pos0 is not None:
+            ops.rows_add_bf16(dhid, dec_pos0[1], dec_pos0[0], dec_pos0[2])   # rows are unique: plain bf16 read-modify-write
         if self.grad_hook is not None:
             self.grad_hook("other", -1)
 
         # ---- backbone
         dh0 = self.backbone.backward(dhid, B, S, tr["backbone"], 1.0, on_layer_done=self.grad_hook)
         if train_embeddings:
-            ops.embed_bwd(s["tk"], s["mk"], dh0, d_text, d_audio, V)
-            ops.f32_to_bf16(d_text.view(-1), m.block("text_embeddings.weight", True).view(-1), accumulate=True)
-            ops.f32_to_bf16(d_audio.view(-1), m.block("audio_embeddings.weight", True).view(-1), accumulate=True)
+            self._embedding_backward(s, dh0, dseq if (dec is not None and s["aw"] != 0.0) else None)
         if self.grad_hook is not None:
             self.grad_hook("embeddings", -1)
+
+    def _embedding_backward(self, s, dh0, dseq):
+        """d(text_embeddings), d(audio_embeddings): every (embedding row, gradient source row) occurrence - live slots of
+        the backbone input and, when the decoder was trained, positions 1..K-1 of its input - is sorted by embedding row
+        (torch.sort: no host sync) and reduced by ``csm_embed_bwd_sorted`` in a fixed order, straight into the bf16
+        gradient arena."""
+        m, a = self.m, self.m.args
+        dev = m.device
+        K, V = a.audio_num_codebooks, a.audio_vocab_size
+        TV = a.text_vocab_size
+        n_rows = TV + K * V
+        tk, mk = s["tk"], s["mk"]
+        M = tk.shape[0]
+        slot = torch.arange(K + 1, device=dev)
+        rows = torch.where(slot < K, TV + tk + slot * V, tk)                 # [M, K+1] combined row id
+        rows = torch.where(mk.bool(), rows, torch.full_like(rows, n_rows))   # masked-out slots -> padding id
+        src = torch.arange(M, device=dev).unsqueeze(1).expand(M, K + 1)
+        rows, src = rows.reshape(-1), src.reshape(-1)
+        if dseq is not None:
+            codes, N = s["dec"]["codes"], s["dec"]["N"]
+            r2 = TV + codes[:, :K - 1] + torch.arange(K - 1, device=dev) * V                      # [N, K-1]
+            s2 = M + torch.arange(N, device=dev).unsqueeze(1) * K + torch.arange(1, K, device=dev)
+            rows, src = torch.cat([rows, r2.reshape(-1)]), torch.cat([src, s2.reshape(-1)])
+        order = torch.argsort(rows, stable=True)
+        ops.embed_bwd_sorted(rows[order].contiguous(), src[order].contiguous(), dh0, dseq,
+                             m.block("text_embeddings.weight", True), m.block("audio_embeddings.weight", True))
 
     # -------------------------------------------------------------------------------------------- generation
     @torch.no_grad()

@@ -124,6 +124,18 @@ def embed_bwd(tokens, mask_u8, dh, d_text_f32, d_audio_f32, audio_vocab):
                             d_audio_f32.data_ptr(), M, K1 - 1, dh.shape[1], audio_vocab, _stream()), "csm_embed_bwd")
 
 
+def embed_bwd_sorted(sorted_rows, src_index, dh, dseq, g_text, g_audio):
+    assert sorted_rows.dtype == torch.int64 and src_index.dtype == torch.int64 and sorted_rows.is_contiguous() and src_index.is_contiguous()
+    check(lib.csm_embed_bwd_sorted(sorted_rows.data_ptr(), src_index.data_ptr(), sorted_rows.numel(), dh.data_ptr(), _ptr(dseq),
+                                   dh.shape[0], g_text.data_ptr(), g_audio.data_ptr(), g_text.shape[0],
+                                   g_text.shape[0] + g_audio.shape[0], dh.shape[1], _stream()), "csm_embed_bwd_sorted")
+
+
+def rows_add_bf16(dst, rows_i32, src, src_stride_rows):
+    check(lib.csm_rows_add_bf16(dst.data_ptr(), rows_i32.data_ptr(), src.data_ptr(), rows_i32.numel(), int(src_stride_rows),
+                                dst.shape[1], _stream()), "csm_rows_add_bf16")
+
+
 def decoder_input_fwd(hidden, rows_i32, codes, audio_emb, out, audio_vocab):
     N, K = codes.shape
     assert rows_i32.dtype == torch.int32 and codes.dtype == torch.int64 and codes.is_contiguous()

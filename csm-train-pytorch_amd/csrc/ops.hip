@@ -266,6 +266,74 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
     }
 }
 
+// Deterministic, scratch-free embedding backward: the (row, source) occurrence list is sorted by embedding row on the
+// host side (torch.sort, no sync); one wave per occurrence index, only the FIRST occurrence of a row does work: it sums
+// the bf16 gradient rows of every occurrence of that row in fp32 registers (fixed order) and adds the result into the
+// bf16 gradient table once.  Sources: index < M -> dh[index] (backbone input gradient), else dseq[index - M]
+// (depth-decoder input gradient).  Rows >= n_rows are padding (masked-out slots).
+template <int NC>
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const long long* __restrict__ rows, const long long* __restrict__ src,
+                                                               long long n_occ, const bf16_t* __restrict__ dh,
+                                                               const bf16_t* __restrict__ dseq, long long M,
+                                                               bf16_t* __restrict__ g_text, bf16_t* __restrict__ g_audio,
+                                                               long long text_rows, long long n_rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_occ) return;
+    const long long r = rows[i];
+    if (r >= n_rows || (i > 0 && rows[i - 1] == r)) return;      // padding, or not the first occurrence of this row
+    float acc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+    const int nchunk = D >> 3;
+    for (long long k = i; k < n_occ && rows[k] == r; ++k) {
+        const long long sidx = src[k];
+        const bf16_t* p = sidx < M ? dh + (size_t)sidx * D : dseq + (size_t)(sidx - M) * D;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                float f[8];
+                unpack8(*reinterpret_cast<const U4*>(p + ch * 8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c][j] += f[j];
+            }
+        }
+    }
+    bf16_t* dst = r < text_rows ? g_text + (size_t)r * D : g_audio + (size_t)(r - text_rows) * D;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            float f[8];
+            unpack8(*reinterpret_cast<const U4*>(dst + ch * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += acc[c][j];
+            *reinterpret_cast<U4*>(dst + ch * 8) = pack8(f);
+        }
+    }
+}
+
+// dst[rows[n]][:] += src[n * src_stride_rows][:]   (rows are unique: no atomics; one wave per n)
+__global__ __launch_bounds__(256) void rows_add_kernel(bf16_t* __restrict__ dst, const int* __restrict__ rows,
+                                                       const bf16_t* __restrict__ src, long long N, int src_stride_rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    bf16_t* d = dst + (size_t)rows[n] * D;
+    const bf16_t* s = src + (size_t)n * src_stride_rows * D;
+    for (int c0 = lane * 8; c0 < D; c0 += 512) {
+        float a[8], b[8];
+        unpack8(*reinterpret_cast<const U4*>(d + c0), a);
+        unpack8(*reinterpret_cast<const U4*>(s + c0), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        *reinterpret_cast<U4*>(d + c0) = pack8(a);
+    }
+}
+
 // build the depth-decoder input rows [N][K][D]: position 0 = backbone state h[row], position i>=1 = audio_emb of
 // code i-1 of the target frame (teacher forcing of reference src/csm/models/model.py:175-189).
 __global__ __launch_bounds__(256) void decoder_input_kernel(const bf16_t* __restrict__ hidden, const int* __restrict__ rows,
@@ -525,6 +593,30 @@ extern "C" int csm_embed_bwd(const long long* tokens, const uint8_t* mask, const
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, tokens, mask, (const bf16_t*)dh, d_text,
                        d_audio, K, D, audio_vocab);
     CSM_CHECK_LAUNCH("csm_embed_bwd");
+    return 0;
+}
+
+extern "C" int csm_embed_bwd_sorted(const long long* sorted_rows, const long long* src_index, long long n_occ, const void* dh,
+                                    const void* dseq, long long M, void* g_text, void* g_audio, long long text_rows,
+                                    long long n_rows, int D, hipStream_t stream) {
+    CSM_REQUIRE(sorted_rows && src_index && dh && g_text && g_audio && n_occ > 0, "csm_embed_bwd_sorted: bad arguments");
+    CSM_REQUIRE((D & 7) == 0 && D <= 4096, "csm_embed_bwd_sorted: D=%d must be a multiple of 8 and <= 4096", D);
+    const long long blocks = (n_occ + 3) / 4;
+    CSM_REQUIRE(blocks < (1ll << 31), "csm_embed_bwd_sorted: too many occurrences");
+    const int nc = (D + 511) / 512;
+#define L(NC) hipLaunchKernelGGL((embed_bwd_sorted_kernel<NC>), dim3((unsigned)blocks), dim3(256), 0, stream, sorted_rows, src_index, n_occ, (const bf16_t*)dh, (const bf16_t*)dseq, M, (bf16_t*)g_text, (bf16_t*)g_audio, text_rows, n_rows, D)
+    if (nc <= 1) L(1); else if (nc <= 2) L(2); else if (nc <= 4) L(4); else L(8);
+#undef L
+    CSM_CHECK_LAUNCH("csm_embed_bwd_sorted");
+    return 0;
+}
+
+extern "C" int csm_rows_add_bf16(void* dst, const int* rows, const void* src, long long N, int src_stride_rows, int D,
+                                 hipStream_t stream) {
+    CSM_REQUIRE(dst && rows && src && N > 0 && (D & 7) == 0 && src_stride_rows > 0, "csm_rows_add_bf16: bad arguments");
+    hipLaunchKernelGGL(rows_add_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, (bf16_t*)dst, rows, (const bf16_t*)src,
+                       N, src_stride_rows, D);
+    CSM_CHECK_LAUNCH("csm_rows_add_bf16");
     return 0;
 }
 

@@ -75,6 +75,15 @@ int csm_embed_fwd(const long long* tokens, const uint8_t* mask, const void* text
 int csm_embed_bwd(const long long* tokens, const uint8_t* mask, const void* dh, float* d_text, float* d_audio,
                   long long M, int K, int D, int audio_vocab, csm_stream_t stream);
 
+/* Deterministic, scratch-free form of the embedding backward: occurrences (embedding row, source row) sorted by
+ * embedding row; text rows are [0, text_rows), audio rows follow; rows >= n_rows are padding.  Source index < M reads
+ * dh[index], otherwise dseq[index - M].  Sums in fp32 registers, adds into the bf16 gradient tables once per row. */
+int csm_embed_bwd_sorted(const long long* sorted_rows, const long long* src_index, long long n_occ, const void* dh,
+                         const void* dseq, long long M, void* g_text, void* g_audio, long long text_rows, long long n_rows,
+                         int D, csm_stream_t stream);
+/* dst[rows[n]] += src[n * src_stride_rows] for unique rows (scatter of the decoder's position-0 gradient) */
+int csm_rows_add_bf16(void* dst, const int* rows, const void* src, long long N, int src_stride_rows, int D, csm_stream_t stream);
+
 /* depth-decoder teacher forcing (model.py:175-189): out[n][0]=hidden[rows[n]], out[n][i]=audio_emb[code_{i-1}+(i-1)V] */
 int csm_decoder_input_fwd(const void* hidden, const int* rows, const long long* codes, const void* audio_emb, void* out,
                           long long N, int K, int D, int audio_vocab, csm_stream_t stream);

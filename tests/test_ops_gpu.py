@@ -286,6 +286,29 @@ def test_embed(dev):
     ops.embed_bwd(tk, mk, dh.to(dev), dt, da, cfg.audio_vocab)
     close("embed d_text", dt, pt["text_embeddings.weight"].grad, 1e-5)
     close("embed d_audio", da, pt["audio_embeddings.weight"].grad, 1e-5)
+    # sorted / deterministic form, with extra occurrences coming from a second source tensor
+    K, V, TV = cfg.n_codebooks, cfg.audio_vocab, cfg.text_vocab
+    slot = torch.arange(K + 1)
+    tk2 = tokens.view(M, -1)
+    rows = torch.where(slot < K, TV + tk2 + slot * V, tk2)
+    rows = torch.where(mask.view(M, -1), rows, torch.full_like(rows, TV + K * V))
+    src = torch.arange(M).unsqueeze(1).expand(M, K + 1)
+    g2 = torch.Generator().manual_seed(10)
+    extra_rows = TV + torch.randint(0, K * V, (50,), generator=g2)
+    dseq = rnd((50, cfg.backbone.dim), g2)
+    rows_all = torch.cat([rows.reshape(-1), extra_rows])
+    src_all = torch.cat([src.reshape(-1), M + torch.arange(50)])
+    order = torch.argsort(rows_all, stable=True)
+    gt = torch.ones_like(te)      # accumulate on top of existing gradient values
+    ga = torch.ones_like(ae)
+    ops.embed_bwd_sorted(rows_all[order].contiguous().to(dev), src_all[order].contiguous().to(dev), dh.to(dev), dseq.to(dev), gt, ga)
+    ref_a = pt["audio_embeddings.weight"].grad.clone()
+    ref_a.index_add_(0, extra_rows - TV, dseq.float())
+    close("embed sorted d_text", gt, 1.0 + pt["text_embeddings.weight"].grad, 1e-2)
+    close("embed sorted d_audio", ga, 1.0 + ref_a, 1e-2)
+    gt2, ga2 = torch.ones_like(te), torch.ones_like(ae)
+    ops.embed_bwd_sorted(rows_all[order].contiguous().to(dev), src_all[order].contiguous().to(dev), dh.to(dev), dseq.to(dev), gt2, ga2)
+    assert torch.equal(gt, gt2) and torch.equal(ga, ga2), "sorted embedding backward must be bitwise repeatable"
 
 
 def test_ce(dev):
