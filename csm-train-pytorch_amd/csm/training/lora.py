@@ -34,12 +34,29 @@ class LoRAAdapter:
         ops.gemm(t, self.B, y, y, alpha=self.scaling)
         return t
 
+    @staticmethod
+    def _skinny_wgrad(a, b, out, alpha):
+        """out[Ma, Nb] += alpha * a[M, Ma]^T b[M, Nb] where one of Ma / Nb is the LoRA rank: the output has a handful of
+        tiles and a very long contraction, so the contraction is split over the batch dimension of the GEMM (fp32
+        partial slabs) and summed by the column-sum kernel - otherwise 16 workgroups would walk M = 16k rows serially."""
+        M = a.shape[0]
+        chunk = 256
+        nsplit = M // chunk
+        if nsplit < 8 or M % chunk:
+            ops.gemm(a, b, out, out, True, True, alpha=alpha)
+            return
+        Ma, Nb = a.shape[1], b.shape[1]
+        part = torch.empty(nsplit, Ma * Nb, dtype=torch.float32, device=a.device)
+        ops.gemm(a[:chunk], b[:chunk], part[0].view(Ma, Nb), None, True, True, alpha=alpha, batch=nsplit,
+                 sA=chunk * a.stride(0), sB=chunk * b.stride(0), sC=Ma * Nb)
+        ops.colsum_bf16(part, out.view(-1), accumulate=True)
+
     def backward(self, x, dy, t, dx):
         """dB += s dy^T t ; dt = s dy B ; dA += dt^T x ; dx += dt A."""
         dt = torch.empty_like(t)
         ops.gemm(dy, self.B, dt, None, False, True, alpha=self.scaling)
-        ops.gemm(dy, t, self.gB, self.gB, True, True, alpha=self.scaling)
-        ops.gemm(dt, x, self.gA, self.gA, True, True)
+        self._skinny_wgrad(dy, t, self.gB, self.scaling)
+        self._skinny_wgrad(dt, x, self.gA, 1.0)
         ops.gemm(dt, self.A, dx, dx, False, True)
 
 
