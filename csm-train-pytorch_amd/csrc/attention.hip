@@ -135,9 +135,24 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
     auto v_img = [&](int st) { return smem + st * NIMG * I::BYTES + I::BYTES; };      // fwd: V tr image; bwd: V row image
     auto k_tr = [&](int st) { return smem + st * NIMG * I::BYTES + 2 * I::BYTES; };   // bwd only
 
-    const int qb = gridDim.x - 1 - blockIdx.x;  // heaviest (most key blocks) first
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int kvh = h / (H / KV);
+    // 1-D grid, XCD-aware: workgroup ids are dealt round-robin over the 8 XCDs; the bijective remap below hands every
+    // XCD a contiguous run of work items, ordered (batch, kv-head) pair -> q-head of the group -> q-block (heaviest
+    // first), so the workgroups resident on one XCD read the same K/V panels through the same 4-MiB L2.
+    const int nqblk = (S + 64 * QT - 1) / (64 * QT);
+    const int rep_ = H / KV;
+    const int per_pair = rep_ * nqblk;
+    int pair, local;
+    {
+        const int T = gridDim.x, id = blockIdx.x, xcd = id & 7, within = id >> 3;
+        const int q8 = T >> 3, r8 = T & 7;
+        const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+        pair = nid / per_pair;
+        local = nid % per_pair;
+    }
+    const int qb = nqblk - 1 - (local % nqblk);
+    const int kvh_ = pair % KV, b = pair / KV;
+    const int h = kvh_ * rep_ + local / nqblk;
+    const int kvh = kvh_;
     const int ld = (H + 2 * KV) * HD;
     const bf16_t* Qp = qkv + (size_t)b * S * ld + h * HD;
     const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * HD;
@@ -331,7 +346,18 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
     auto do_tr = [&](int st) { return smem + st * STAGE + 3 * I::BYTES; };
     auto stat = [&](int st) { return reinterpret_cast<float*>(smem + st * STAGE + 4 * I::BYTES); };  // [0..63] lse*log2e, [64..127] delta
 
-    const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    // 1-D XCD-aware grid (see attn_q_kernel): contiguous run of (batch, kv-head) pairs per XCD, heaviest key block first
+    const int nkblk = (S + KB - 1) / KB;
+    int kblk, kvh, b;
+    {
+        const int T = gridDim.x, id = blockIdx.x, xcd = id & 7, within = id >> 3;
+        const int q8 = T >> 3, r8 = T & 7;
+        const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+        const int pair = nid / nkblk;
+        kblk = nid % nkblk;
+        kvh = pair % KV;
+        b = pair / KV;
+    }
     const int rep = H / KV;
     const int ld = (H + 2 * KV) * HD, ldo = H * HD;
     const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * HD;
@@ -510,7 +536,7 @@ static void launch_q(const void* qkv, void* out, float* lse, const void* dout, c
     static bool done = false;
     if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
     done = true;
-    dim3 grid((S + 64 * QT - 1) / (64 * QT), H, B), block(256);
+    dim3 grid((unsigned)(((S + 64 * QT - 1) / (64 * QT)) * H * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (const bf16_t*)dout, delta,
                        (bf16_t*)dqkv, S, H, KV, scale);
 }
@@ -523,7 +549,7 @@ static void launch_dkv(const void* qkv, const void* dout, const float* lse, cons
     static bool done = false;
     if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
     done = true;
-    dim3 grid((S + 64 * KT - 1) / (64 * KT), KV, B), block(256);
+    dim3 grid((unsigned)(((S + 64 * KT - 1) / (64 * KT)) * KV * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, S, H, KV,
                        scale);
 }
