@@ -68,14 +68,20 @@ class _Stack:
             hn = torch.empty(M, d, dtype=BF16, device=dev)
             rstd2 = torch.empty(M, dtype=F32, device=dev)
             ops.rmsnorm_fwd(h, self.w(f"layers.{i}.mlp_norm.scale"), hn, rstd2, c.norm_eps)
-            gu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
-            ops.linear_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu)
-            for mod, lo_, hi_ in (("w1", 0, F), ("w3", F, 2 * F)):
-                ad = self._lora(i, mod)
-                if ad is not None:
-                    a[f"t_{mod}"] = ad.forward(hn, gu[:, lo_:hi_])
+            gu = torch.empty(M, 2 * F, dtype=BF16, device=dev)     # gate/up interleaved: g0,u0,g1,u1,...
             act = torch.empty(M, F, dtype=BF16, device=dev)
-            ops.swiglu_fwd(gu, act)
+            ad1, ad3 = self._lora(i, "w1"), self._lora(i, "w3")
+            if ad1 is None and ad3 is None:
+                ops.linear_swiglu_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu, act)   # activation fused into the GEMM epilogue
+            else:
+                ops.linear_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu)
+                gv = gu.view(M, F, 2)
+                for mod, col, ad in (("w1", 0, ad1), ("w3", 1, ad3)):
+                    if ad is not None:
+                        tmp = torch.zeros(M, F, dtype=BF16, device=dev)
+                        a[f"t_{mod}"] = ad.forward(hn, tmp)
+                        gv[:, :, col] += tmp
+                ops.swiglu_fwd(gu, act)
             out = torch.empty(M, d, dtype=BF16, device=dev)
             ops.linear_fwd(act, self.w(f"layers.{i}.mlp.w2.weight"), out, residual=h)
             ad = self._lora(i, "w2")
@@ -118,22 +124,24 @@ class _Stack:
             a = self.acts[i]
             hq, hk = H * hd, KV * hd
             # ---- MLP: out = h + w2(act)
-            dact = torch.empty(M, F, dtype=BF16, device=dev)
-            ops.linear_dx(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact)
+            dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
             ad = self._lora(i, "w2")
-            if ad is not None:
+            if ad is None:
+                ops.linear_dx_swiglu_bwd(dx, self.w(f"layers.{i}.mlp.w2.weight"), a["gu"], dgu)   # d(act) never stored
+            else:
+                dact = torch.empty(M, F, dtype=BF16, device=dev)
+                ops.linear_dx(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact)
                 ad.backward(a["act"], dx, a["t_w2"], dact)
+                ops.swiglu_bwd(a["gu"], dact, dgu)
+                del dact
             if train_base:
                 ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=True, alpha=alpha)
-            dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
-            ops.swiglu_bwd(a["gu"], dact, dgu)
-            del dact
             dhn = torch.empty(M, d, dtype=BF16, device=dev)
             ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
-            for mod, lo_, hi_ in (("w1", 0, F), ("w3", F, 2 * F)):
+            for mod, col in (("w1", 0), ("w3", 1)):
                 ad = self._lora(i, mod)
                 if ad is not None:
-                    ad.backward(a["hn"], dgu[:, lo_:hi_], a[f"t_{mod}"], dhn)
+                    ad.backward(a["hn"], dgu.view(M, F, 2)[:, :, col].contiguous(), a[f"t_{mod}"], dhn)
             if train_base:
                 ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=True, alpha=alpha)
             del dgu

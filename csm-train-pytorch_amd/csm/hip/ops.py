@@ -44,6 +44,24 @@ def gemm(A, B, C, R=None, transA=False, transB=False, alpha=1.0, batch=1, sA=0, 
     return C
 
 
+def linear_swiglu_fwd(x, w13, gu, act):
+    """gu[M,2F] = x w13^T with gate/up interleaved, act[M,F] = silu(gate)*up, one GEMM launch."""
+    pa, M, K, lda = _mat(x)
+    pb, N, Kb, ldb = _mat(w13)
+    assert K == Kb and gu.shape == (M, N) and act.shape == (M, N // 2) and gu.is_contiguous() and act.is_contiguous()
+    check(lib.csm_gemm_bf16_ex(pa, pb, gu.data_ptr(), None, M, N, K, lda, ldb, N, 0, 0, 0, 0, 1.0, 1, 0, 0, 0, 0, 1, None,
+                               act.data_ptr(), N // 2, _stream()), "csm_gemm_bf16_ex(swiglu fwd)")
+
+
+def linear_dx_swiglu_bwd(dy, w2, gu, dgu):
+    """dgu[M,2F] = SwiGLU'(gu) applied to (dy[M,d] w2[d,F]); the intermediate d(act) is never stored."""
+    pa, M, K, lda = _mat(dy)
+    pb, Kb, F, ldb = _mat(w2)
+    assert K == Kb and gu.shape == (M, 2 * F) and dgu.shape == (M, 2 * F) and gu.is_contiguous() and dgu.is_contiguous()
+    check(lib.csm_gemm_bf16_ex(pa, pb, dgu.data_ptr(), None, M, F, K, lda, ldb, 2 * F, 0, 0, 1, 0, 1.0, 1, 0, 0, 0, 0, 2,
+                               gu.data_ptr(), None, 2 * F, _stream()), "csm_gemm_bf16_ex(swiglu bwd)")
+
+
 def linear_fwd(x, w, out, residual=None, alpha=1.0):
     """out[M,N] = x[M,K] w[N,K]^T (+ residual)."""
     return gemm(x, w, out, residual, False, False, alpha)

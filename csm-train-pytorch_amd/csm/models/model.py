@@ -4,7 +4,7 @@
 ``_embed_tokens``), ``sample_topk``, ``_create_causal_mask`` and ``_index_causal_mask`` keep the reference's names,
 arguments and state-dict keys (torchtune naming: ``backbone.layers.{i}.attn.q_proj.weight`` ...), but nothing
 underneath is torchtune: the parameters are views into flat bf16 arenas laid out for the HIP kernels
-(fused q|k|v and w1|w3 blocks, vocabulary padded to a multiple of 64 for the head GEMMs) and every forward /
+(fused q|k|v block, w1/w3 rows interleaved in one block, vocabulary padded to a multiple of 64 for the head GEMMs) and every forward /
 backward op is a launch into ``libcsm_hip.so``.
 
 HBM layout (one contiguous bf16 arena, one matching bf16 gradient arena; optimiser keeps fp32 master/m/v):
@@ -223,9 +223,9 @@ class Model(nn.Module):
                 out[f"{p}.attn.k_proj.weight"] = qkv[hq:hq + hk]
                 out[f"{p}.attn.v_proj.weight"] = qkv[hq + hk:]
                 out[f"{p}.attn.output_proj.weight"] = blk(f"{p}.attn.output_proj.weight")
-                out[f"{p}.mlp.w1.weight"] = w13[:c.intermediate_dim]
+                out[f"{p}.mlp.w1.weight"] = w13[0::2]       # gate rows and up rows are interleaved (SwiGLU GEMM epilogue)
                 out[f"{p}.mlp.w2.weight"] = blk(f"{p}.mlp.w2.weight")
-                out[f"{p}.mlp.w3.weight"] = w13[c.intermediate_dim:]
+                out[f"{p}.mlp.w3.weight"] = w13[1::2]
                 out[f"{p}.sa_norm.scale"] = blk(f"{p}.sa_norm.scale")
                 out[f"{p}.mlp_norm.scale"] = blk(f"{p}.mlp_norm.scale")
             out[f"{prefix}.norm.scale"] = blk(f"{prefix}.norm.scale")

@@ -112,9 +112,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] per 16x16 tile ----------
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
-    const bf16_t* R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (!R || (g.ldr & 3) == 0);
+    Epi e;
+    e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
+    e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
+    e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
+    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm0 + 16 * i + (lane & 15);
@@ -123,29 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn0 + 16 * j + 4 * (lane >> 4);
             if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha,
-                          acc[i][j][3] * g.alpha};
-            if (vec_ok && n + 3 < g.N) {
-                if (R) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + (size_t)m * g.ldr + n);
-                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-                }
-                if constexpr (sizeof(OutT) == 2) {
-                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = o;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-                }
-            } else {
-                for (int e = 0; e < 4 && n + e < g.N; ++e) {
-                    float x = v[e];
-                    if (R) x += bf2f(R[(size_t)m * g.ldr + n + e]);
-                    if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(C)[(size_t)m * g.ldc + n + e] = f2bf(x);
-                    else reinterpret_cast<float*>(C)[(size_t)m * g.ldc + n + e] = x;
-                }
-            }
+            epi_store<OutT>(e, vec_ok, m, n, acc[i][j]);
         }
     }
 }
@@ -172,7 +153,8 @@ int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
 
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                        int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
-                       long long sC, long long sR, hipStream_t stream);
+                       long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
+                       hipStream_t stream);
 
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
@@ -195,10 +177,12 @@ extern "C" int csm_set_gemm_variant(int v) {
     return 0;
 }
 
-extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
-                             int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
-                             long long strideA, long long strideB, long long strideC, long long strideR,
-                             hipStream_t stream) {
+// epilogue: 0 none; 1 SwiGLU forward (C = gate/up interleaved [M][N], aux_out = act [M][N/2]); 2 SwiGLU backward
+// (GEMM computes d(act) [M][N]; aux_in = gate/up [M][2N]; C = d(gate/up) interleaved [M][2N], ldc >= 2N)
+extern "C" int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                                int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
+                                long long strideA, long long strideB, long long strideC, long long strideR, int epilogue,
+                                const void* aux_in, void* aux_out, int ld_aux, hipStream_t stream) {
     CSM_REQUIRE(A && B && C, "csm_gemm_bf16: null operand");
     CSM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "csm_gemm_bf16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     CSM_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "csm_gemm_bf16: lda/ldb must be multiples of 8 (lda=%d ldb=%d)", lda, ldb);
@@ -208,18 +192,30 @@ extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* 
     else CSM_REQUIRE((M & 7) == 0, "csm_gemm_bf16: M must be a multiple of 8 when A is [K][M] (M=%d)", M);
     if (!transB) CSM_REQUIRE((K & 7) == 0, "csm_gemm_bf16: K must be a multiple of 8 when B is [N][K] (K=%d)", K);
     else CSM_REQUIRE((N & 7) == 0, "csm_gemm_bf16: N must be a multiple of 8 when B is [K][N] (N=%d)", N);
-    CSM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, "csm_gemm_bf16: leading dimension too small");
+    CSM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= (epilogue == 2 ? 2 * N : N), "csm_gemm_bf16: leading dimension too small");
+    if (epilogue == 1) CSM_REQUIRE(!out_f32 && aux_out && (N & 3) == 0 && (ldc & 3) == 0 && ld_aux >= N / 2 && (ld_aux & 1) == 0 && !R, "csm_gemm_bf16_ex: bad SwiGLU-forward epilogue arguments");
+    if (epilogue == 2) CSM_REQUIRE(!out_f32 && aux_in && (N & 3) == 0 && (ldc & 7) == 0 && (ld_aux & 7) == 0 && ld_aux >= 2 * N && !R && ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)C & 15) == 0, "csm_gemm_bf16_ex: bad SwiGLU-backward epilogue arguments");
+    CSM_REQUIRE(epilogue >= 0 && epilogue <= 2, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 3 && K % 64 == 0 && M >= 8 && N >= 8))
         return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
-                                  strideB, strideC, strideR, stream);
+                                  strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream);
     GemmArgs g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sR = strideR;
     g.alpha = alpha;
+    g.epi_mode = epilogue; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
     if (!transA && !transB) return launch<0, 0>(g, out_f32, batch, stream);
     if (!transA && transB) return launch<0, 1>(g, out_f32, batch, stream);
     if (transA && transB) return launch<1, 1>(g, out_f32, batch, stream);
     return launch<1, 0>(g, out_f32, batch, stream);
+}
+
+extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                             int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
+                             long long strideA, long long strideB, long long strideC, long long strideR,
+                             hipStream_t stream) {
+    return csm_gemm_bf16_ex(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA, strideB,
+                            strideC, strideR, 0, nullptr, nullptr, 0, stream);
 }

@@ -26,6 +26,7 @@ struct Gemm256Args {
     long long sA, sB, sC, sR;
     float alpha;
     int tiles_m, tiles_n;
+    int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
 };
 
 // one 16-KiB half-tile by LDS-DMA: 16 pieces of 1 KiB over 8 waves
@@ -149,9 +150,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args g) {
 #undef MFMA_QUAD
 
     // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] of each 16x16 tile
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
-    const bf16_t* R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (!R || (g.ldr & 3) == 0);
+    Epi e;
+    e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
+    e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
+    e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
+    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + 16 * i + (lane & 15);
@@ -160,30 +164,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args g) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + 16 * j + 4 * (lane >> 4);
             if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
-            if (vec_ok && n + 3 < g.N) {
-                if (R) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + (size_t)m * g.ldr + n);
-                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-                }
-                if constexpr (sizeof(OutT) == 2) {
-                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = o;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            } else {
-                for (int e = 0; e < 4 && n + e < g.N; ++e) {
-                    float x = v[e];
-                    if (R) x += bf2f(R[(size_t)m * g.ldr + n + e]);
-                    if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(C)[(size_t)m * g.ldc + n + e] = f2bf(x);
-                    else reinterpret_cast<float*>(C)[(size_t)m * g.ldc + n + e] = x;
-                }
-            }
+            epi_store<OutT>(e, vec_ok, m, n, acc[i][j]);
         }
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Variant with register-level software pipelining: a phase multiplies ONE pair of A m-tiles (32 rows) by all four B
@@ -285,9 +270,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     }
 #undef MFMA_PAIR
 
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
-    const bf16_t* R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (!R || (g.ldr & 3) == 0);
+    Epi e;
+    e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
+    e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
+    e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
+    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + 16 * i + (lane & 15);
@@ -296,30 +284,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + 16 * j + 4 * (lane >> 4);
             if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
-            if (vec_ok && n + 3 < g.N) {
-                if (R) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(R + (size_t)m * g.ldr + n);
-                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-                }
-                if constexpr (sizeof(OutT) == 2) {
-                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (size_t)m * g.ldc + n) = o;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            } else {
-                for (int e = 0; e < 4 && n + e < g.N; ++e) {
-                    float x = v[e];
-                    if (R) x += bf2f(R[(size_t)m * g.ldr + n + e]);
-                    if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(C)[(size_t)m * g.ldc + n + e] = f2bf(x);
-                    else reinterpret_cast<float*>(C)[(size_t)m * g.ldc + n + e] = x;
-                }
-            }
+            epi_store<OutT>(e, vec_ok, m, n, acc[i][j]);
         }
     }
 }
+
 
 int g_gemm256_pipelined = 1;
 
@@ -360,8 +329,10 @@ void csm_gemm256_set_pipelined(int v) { g_gemm256_pipelined = v; }
 // called by csm_gemm_bf16 (gemm.hip) when the tile heuristic picks the 256x256 kernel; same argument meaning
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                        int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
-                       long long sC, long long sR, hipStream_t stream) {
+                       long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
+                       hipStream_t stream) {
     Gemm256Args g;
+    g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sA = sA; g.sB = sB; g.sC = sC; g.sR = sR; g.alpha = alpha;

@@ -17,6 +17,7 @@ struct GemmArgs {
     long long sA, sB, sC, sR;  // batch strides in elements
     float alpha;
     int tiles_m, tiles_n;
+    int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
 };
 
 // ---- staging: each thread moves 4 x 16 B per operand per K-tile --------------------------------
@@ -164,5 +165,62 @@ struct Frags {
         else return cat4(tr[i][ks].lo, tr[i][ks].hi);
     }
 };
+
+// ---- epilogue ------------------------------------------------------------------------------------------------
+// One 16x16 accumulator: the lane owns C[m][n .. n+3].  mode 0: C = alpha*acc (+R).  mode 1 (SwiGLU forward, bf16 out,
+// gate/up interleaved along n): additionally aux_out[m][n/2 .. n/2+1] = silu(gate) * up.  mode 2 (SwiGLU backward,
+// GEMM N = F): acc is d(act)[m][n..n+3]; reads gate/up from aux_in[m][2n .. 2n+7] and writes d(gate),d(up)
+// interleaved to C[m][2n .. 2n+7] (C is [M][2F]); d(act) itself is never stored.
+struct Epi {
+    void* C; const bf16_t* R; int ldc, ldr; float alpha;
+    int mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
+    int M, N;
+};
+enum { EPI_NONE = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2 };
+
+template <typename OutT>
+__device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int n, const f32x4& a) {
+    float v[4] = {a[0] * e.alpha, a[1] * e.alpha, a[2] * e.alpha, a[3] * e.alpha};
+    if (e.mode == EPI_SWIGLU_BWD) {
+        if constexpr (sizeof(OutT) == 2) {
+            float g[8], o[8];
+            unpack8(*reinterpret_cast<const U4*>(e.aux_in + (size_t)m * e.ld_aux + 2 * n), g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float gt = g[2 * i], up = g[2 * i + 1];
+                const float sg = 1.f / (1.f + __expf(-gt));
+                o[2 * i] = v[i] * up * sg * (1.f + gt * (1.f - sg));
+                o[2 * i + 1] = v[i] * gt * sg;
+            }
+            *reinterpret_cast<U4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + 2 * n) = pack8(o);
+        }
+        return;
+    }
+    if (vec_ok && n + 3 < e.N) {
+        if (e.R) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(e.R + (size_t)m * e.ldr + n);
+            v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+            v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+        }
+        if constexpr (sizeof(OutT) == 2) {
+            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;
+            if (e.mode == EPI_SWIGLU_FWD) {
+                const float a0 = v[0] / (1.f + __expf(-v[0])) * v[1];
+                const float a1 = v[2] / (1.f + __expf(-v[2])) * v[3];
+                *reinterpret_cast<uint32_t*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = pack2bf(a0, a1);
+            }
+        } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.C) + (size_t)m * e.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (int k = 0; k < 4 && n + k < e.N; ++k) {
+            float x = v[k];
+            if (e.R) x += bf2f(e.R[(size_t)m * e.ldr + n + k]);
+            if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(e.C)[(size_t)m * e.ldc + n + k] = f2bf(x);
+            else reinterpret_cast<float*>(e.C)[(size_t)m * e.ldc + n + k] = x;
+        }
+    }
+}
 
 }  // namespace

@@ -183,45 +183,47 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
 }
 
 // ------------------------------------------------------------------------------------------------ SwiGLU
-// torchtune FeedForward: w2(silu(w1 x) * w3 x).  gu = [gate | up] ([M][2F]) from the fused w1/w3 GEMM.
+// torchtune FeedForward: w2(silu(w1 x) * w3 x).  gu = fused w1/w3 GEMM output with gate and up INTERLEAVED along the
+// feature axis ([M][2F]: g0,u0,g1,u1,...), the layout the GEMM's SwiGLU epilogues use.  These stand-alone kernels
+// serve the paths the fused epilogues do not cover (LoRA adapters on w1/w3/w2).
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long long M,
                                                          int F) {
-    const int cpr = F >> 3;
+    const int cpr = F >> 2;                       // 4 features (8 interleaved values) per thread
     const long long total = M * cpr;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long row = idx / cpr;
         const int c = (int)(idx % cpr);
-        float g[8], u[8], o[8];
+        float g[8];
         unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + c * 8), g);
-        unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + F + c * 8), u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
-        *reinterpret_cast<U4*>(out + (size_t)row * F + c * 8) = pack8(o);
+        uint2 o;
+        o.x = pack2bf(g[0] / (1.f + __expf(-g[0])) * g[1], g[2] / (1.f + __expf(-g[2])) * g[3]);
+        o.y = pack2bf(g[4] / (1.f + __expf(-g[4])) * g[5], g[6] / (1.f + __expf(-g[6])) * g[7]);
+        *reinterpret_cast<uint2*>(out + (size_t)row * F + c * 4) = o;
     }
 }
 
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dout,
                                                          bf16_t* __restrict__ dgu, long long M, int F) {
-    const int cpr = F >> 3;
+    const int cpr = F >> 2;
     const long long total = M * cpr;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long row = idx / cpr;
         const int c = (int)(idx % cpr);
-        float g[8], u[8], d[8], dg[8], du[8];
+        float g[8], o[8];
         unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + c * 8), g);
-        unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + F + c * 8), u);
-        unpack8(*reinterpret_cast<const U4*>(dout + (size_t)row * F + c * 8), d);
+        const uint2 d2 = *reinterpret_cast<const uint2*>(dout + (size_t)row * F + c * 4);
+        const float d[4] = {__uint_as_float(d2.x << 16), __uint_as_float(d2.x & 0xffff0000u), __uint_as_float(d2.y << 16),
+                            __uint_as_float(d2.y & 0xffff0000u)};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float sg = 1.f / (1.f + __expf(-g[j]));
-            const float silu = g[j] * sg;
-            du[j] = d[j] * silu;
-            dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
+        for (int i = 0; i < 4; ++i) {
+            const float gt = g[2 * i], up = g[2 * i + 1];
+            const float sg = 1.f / (1.f + __expf(-gt));
+            o[2 * i] = d[i] * up * sg * (1.f + gt * (1.f - sg));
+            o[2 * i + 1] = d[i] * gt * sg;
         }
-        *reinterpret_cast<U4*>(dgu + (size_t)row * 2 * F + c * 8) = pack8(dg);
-        *reinterpret_cast<U4*>(dgu + (size_t)row * 2 * F + F + c * 8) = pack8(du);
+        *reinterpret_cast<U4*>(dgu + (size_t)row * 2 * F + c * 8) = pack8(o);
     }
 }
 
@@ -562,7 +564,7 @@ extern "C" int csm_rope(void* qkv, const float* table, const int* pos, long long
 
 extern "C" int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, hipStream_t stream) {
     CSM_REQUIRE(gu && out && M > 0 && F > 0 && (F & 7) == 0, "csm_swiglu_fwd: bad arguments");
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(M * (F >> 3), 256, 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(M * (F >> 2), 256, 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
                        (bf16_t*)out, M, F);
     CSM_CHECK_LAUNCH("csm_swiglu_fwd");
     return 0;
@@ -570,7 +572,7 @@ extern "C" int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, hip
 
 extern "C" int csm_swiglu_bwd(const void* gu, const void* dout, void* dgu, long long M, int F, hipStream_t stream) {
     CSM_REQUIRE(gu && dout && dgu && M > 0 && F > 0 && (F & 7) == 0, "csm_swiglu_bwd: bad arguments");
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * (F >> 3), 256, 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * (F >> 2), 256, 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
                        (const bf16_t*)dout, (bf16_t*)dgu, M, F);
     CSM_CHECK_LAUNCH("csm_swiglu_bwd");
     return 0;

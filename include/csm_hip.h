@@ -40,6 +40,16 @@ int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, i
                   int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long strideA,
                   long long strideB, long long strideC, long long strideR, csm_stream_t stream);
 
+/* Same product with a fused epilogue (bf16 output only):
+ *   epilogue 1, SwiGLU forward : C = [M][N] with gate/up interleaved along N (g0,u0,g1,u1,...) AND aux_out[M][N/2] =
+ *                                silu(gate)*up  - the w1/w3 projection of torchtune FeedForward in one pass;
+ *   epilogue 2, SwiGLU backward: the GEMM result is d(act) [M][N] (never stored); aux_in = gate/up [M][2N]; C receives
+ *                                d(gate),d(up) interleaved [M][2N] (ldc >= 2N) - the w2 dgrad fused with the activation backward. */
+int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                     int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long strideA,
+                     long long strideB, long long strideC, long long strideR, int epilogue, const void* aux_in,
+                     void* aux_out, int ld_aux, csm_stream_t stream);
+
 /* tuning switch (A/B benchmarking): 0 = register staging, 1 = LDS-DMA staging when K % 64 == 0 (default) */
 int csm_set_gemm_variant(int v);
 
@@ -63,7 +73,7 @@ int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, in
 int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                  float* delta_ws /* [B][H][S] */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 
-/* ---- K7: SwiGLU of torchtune FeedForward: out = silu(gate) * up with gu = [gate | up] ([M][2F]) ---------------- */
+/* ---- K7: SwiGLU of torchtune FeedForward: out = silu(gate) * up, gu = gate/up INTERLEAVED ([M][2F]: g0,u0,g1,u1,..) - */
 int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, csm_stream_t stream);
 int csm_swiglu_bwd(const void* gu, const void* dout, void* dgu, long long M, int F, csm_stream_t stream);
 

@@ -198,19 +198,48 @@ def test_rope(dev, hd, H, KV):
 
 
 def test_swiglu(dev):
+    """Stand-alone kernels and the two fused GEMM epilogues; gate/up are interleaved along the feature axis."""
     from csm.hip import ops
     g = torch.Generator().manual_seed(1)
-    M, F = 70, 512
-    gu, dout = rnd((M, 2 * F), g, 2.0), rnd((M, F), g)
-    gr = gu.float().requires_grad_(True)
-    ref = torch.nn.functional.silu(gr[:, :F]) * gr[:, F:]
-    ref.backward(dout.float())
-    out = torch.empty(M, F, dtype=BF, device=dev)
-    ops.swiglu_fwd(gu.to(dev), out)
-    close("swiglu fwd", out, ref, 1e-2)
+    M, F, D = 200, 512, 256
+    x, w1, w3, w2 = rnd((M, D), g), rnd((F, D), g, 0.1), rnd((F, D), g, 0.1), rnd((D, F), g, 0.1)
+    dout = rnd((M, D), g)
+    xr = x.float()
+    gate, up = xr @ w1.float().t(), xr @ w3.float().t()
+    gate_q, up_q = gate.to(BF).float().requires_grad_(True), up.to(BF).float().requires_grad_(True)
+    act_ref = torch.nn.functional.silu(gate_q) * up_q
+    dact_ref = dout.float() @ w2.float()
+    act_ref.backward(dact_ref.to(BF).float())
+    w13 = torch.stack([w1, w3], dim=1).reshape(2 * F, D).contiguous()        # rows: g0,u0,g1,u1,...
+    gu_ref = torch.stack([gate, up], dim=2).reshape(M, 2 * F)
+    dgu_ref = torch.stack([gate_q.grad, up_q.grad], dim=2).reshape(M, 2 * F)
+    # fused forward
+    gu = torch.empty(M, 2 * F, dtype=BF, device=dev)
+    act = torch.empty(M, F, dtype=BF, device=dev)
+    ops.linear_swiglu_fwd(x.to(dev), w13.to(dev), gu, act)
+    close("fused gu", gu, gu_ref, 1e-2)
+    close("fused act", act, act_ref, 1.5e-2)
+    # stand-alone forward on the same gu
+    act2 = torch.empty(M, F, dtype=BF, device=dev)
+    ops.swiglu_fwd(gu, act2)
+    close("swiglu fwd", act2, act_ref, 1.5e-2)
+    # fused backward: dgu = SwiGLU'(gu) . (dout w2)
     dgu = torch.empty(M, 2 * F, dtype=BF, device=dev)
-    ops.swiglu_bwd(gu.to(dev), dout.to(dev), dgu)
-    close("swiglu bwd", dgu, gr.grad, 1e-2)
+    ops.linear_dx_swiglu_bwd(dout.to(dev), w2.to(dev), gu_ref.to(BF).to(dev), dgu)
+    close("fused dgu", dgu, dgu_ref, 2e-2)
+    # stand-alone backward
+    dgu2 = torch.empty(M, 2 * F, dtype=BF, device=dev)
+    ops.swiglu_bwd(gu_ref.to(BF).to(dev), dact_ref.to(BF).to(dev), dgu2)
+    close("swiglu bwd", dgu2, dgu_ref, 1e-2)
+    # the 256x256 kernel's epilogues as well
+    ops.lib.csm_set_gemm_variant(4)
+    try:
+        ops.linear_swiglu_fwd(x.to(dev), w13.to(dev), gu, act)
+        close("fused act (256 kernel)", act, act_ref, 1.5e-2)
+        ops.linear_dx_swiglu_bwd(dout.to(dev), w2.to(dev), gu_ref.to(BF).to(dev), dgu)
+        close("fused dgu (256 kernel)", dgu, dgu_ref, 2e-2)
+    finally:
+        ops.lib.csm_set_gemm_variant(2)
 
 
 def _attn_ref(qkv, B, S, H, KV, hd):
