@@ -20,6 +20,11 @@ from .hip import ops
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+# SwiGLU fused into the GEMM epilogues (csm_gemm_bf16_ex).  A/B on one MI355X box, B=4 S=2048: 88.0 ms/step fused vs
+# 88.9 ms with the stand-alone kernels (the 256x256 GEMM runs one workgroup per CU, so most of the epilogue work is
+# exposed; the gain is what remains after that).  CSM_FUSE_SWIGLU=0 restores the stand-alone path for re-evaluation.
+import os as _os
+FUSE_SWIGLU = _os.environ.get("CSM_FUSE_SWIGLU", "1") == "1"
 
 
 class _Stack:
@@ -71,16 +76,17 @@ class _Stack:
             gu = torch.empty(M, 2 * F, dtype=BF16, device=dev)     # gate/up interleaved: g0,u0,g1,u1,...
             act = torch.empty(M, F, dtype=BF16, device=dev)
             ad1, ad3 = self._lora(i, "w1"), self._lora(i, "w3")
-            if ad1 is None and ad3 is None:
+            if FUSE_SWIGLU and ad1 is None and ad3 is None:
                 ops.linear_swiglu_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu, act)   # activation fused into the GEMM epilogue
             else:
                 ops.linear_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu)
-                gv = gu.view(M, F, 2)
-                for mod, col, ad in (("w1", 0, ad1), ("w3", 1, ad3)):
-                    if ad is not None:
-                        tmp = torch.zeros(M, F, dtype=BF16, device=dev)
-                        a[f"t_{mod}"] = ad.forward(hn, tmp)
-                        gv[:, :, col] += tmp
+                if ad1 is not None or ad3 is not None:
+                    gv = gu.view(M, F, 2)
+                    for mod, col, ad in (("w1", 0, ad1), ("w3", 1, ad3)):
+                        if ad is not None:
+                            tmp = torch.zeros(M, F, dtype=BF16, device=dev)
+                            a[f"t_{mod}"] = ad.forward(hn, tmp)
+                            gv[:, :, col] += tmp
                 ops.swiglu_fwd(gu, act)
             out = torch.empty(M, d, dtype=BF16, device=dev)
             ops.linear_fwd(act, self.w(f"layers.{i}.mlp.w2.weight"), out, residual=h)
@@ -126,12 +132,13 @@ class _Stack:
             # ---- MLP: out = h + w2(act)
             dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
             ad = self._lora(i, "w2")
-            if ad is None:
+            if FUSE_SWIGLU and ad is None:
                 ops.linear_dx_swiglu_bwd(dx, self.w(f"layers.{i}.mlp.w2.weight"), a["gu"], dgu)   # d(act) never stored
             else:
                 dact = torch.empty(M, F, dtype=BF16, device=dev)
                 ops.linear_dx(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact)
-                ad.backward(a["act"], dx, a["t_w2"], dact)
+                if ad is not None:
+                    ad.backward(a["act"], dx, a["t_w2"], dact)
                 ops.swiglu_bwd(a["gu"], dact, dgu)
                 del dact
             if train_base:

@@ -52,7 +52,7 @@ _SIGS = {
     "csm_sumsq_blocks": ([], _i),
     "csm_sumsq_bf16": ([_p, _ll, _p, _p], _i),
     "csm_clip_coef": ([_p, _i, _f, _p, _p], _i),
-    "csm_adamw_step": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _p], _i),
+    "csm_adamw_step": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _i, _p], _i),
     "csm_f32_to_bf16": ([_p, _p, _ll, _i, _p], _i),
     "csm_add_f32_into_bf16": ([_p, _p, _ll, _p], _i),
     "csm_sample_topk": ([_p, _p, _p, _i, _i, _i, _i, _f, _p], _i),

@@ -193,11 +193,11 @@ def clip_coef(partials, max_norm, norm_and_coef):
     check(lib.csm_clip_coef(partials.data_ptr(), partials.numel(), float(max_norm), norm_and_coef.data_ptr(), _stream()), "csm_clip_coef")
 
 
-def adamw_step(master, m, v, param, grad, lr, beta1, beta2, eps, wd, step, norm_and_coef=None, grad_mul=1.0):
+def adamw_step(master, m, v, param, grad, lr, beta1, beta2, eps, wd, step, norm_and_coef=None, grad_mul=1.0, zero_grad=False):
     n = master.numel()
     assert master.dtype == torch.float32 and param.dtype == BF16 and grad.dtype == BF16 and param.numel() == n == grad.numel()
     check(lib.csm_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), param.data_ptr(), grad.data_ptr(), n, lr, beta1,
-                             beta2, eps, wd, int(step), _ptr(norm_and_coef), float(grad_mul), _stream()), "csm_adamw_step")
+                             beta2, eps, wd, int(step), _ptr(norm_and_coef), float(grad_mul), int(zero_grad), _stream()), "csm_adamw_step")
 
 
 def f32_to_bf16(src, dst, accumulate=False):

@@ -104,8 +104,7 @@ class CSMLoRATrainer:
             self.grad_sync.finish()
         if self.max_grad_norm and self.max_grad_norm > 0:
             self.optimizer.clip_grad_norm(self.max_grad_norm)
-        self.optimizer.step()
-        self.optimizer.zero_grad()
+        self.optimizer.step(zero_grad=True)
         return loss.detach()
 
     def train(self, train_dataset, val_dataset=None, batch_size: int = 2, epochs: int = 5, val_every: int = 100,

@@ -84,13 +84,15 @@ class FusedAdamW:
         self._coef = self._norm_coef
         return self._norm_coef[0]
 
-    def step(self):
+    def step(self, zero_grad: bool = False):
+        """One AdamW update.  ``zero_grad=True`` clears the gradients in the same pass over memory (what the trainers
+        use instead of a separate ``zero_grad()``)."""
         self.step_count += 1
         b1, b2 = self.betas
         for g in self.param_groups:
             st = self.state[g["name"]]
             ops.adamw_step(st["master"], st["m"], st["v"], g["param"], g["grad"], g["lr"], b1, b2, self.eps,
-                           g["weight_decay"], self.step_count, self._coef)
+                           g["weight_decay"], self.step_count, self._coef, zero_grad=zero_grad)
         self._coef = None
 
     def state_dict(self):

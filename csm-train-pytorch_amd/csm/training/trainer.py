@@ -96,8 +96,7 @@ class CSMTrainer:
                 self.grad_sync.finish()
             if max_grad_norm and max_grad_norm > 0:
                 self.optimizer.clip_grad_norm(max_grad_norm)
-            self.optimizer.step()
-            self.optimizer.zero_grad()
+            self.optimizer.step(zero_grad=True)
         return loss.detach(), details
 
     def train(self, train_dataset, val_dataset=None, batch_size: int = 2, accumulation_steps: int = 4, epochs: int = 5,

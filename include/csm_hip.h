@@ -110,9 +110,9 @@ int csm_reduce_sum_f32(const float* x, long long n, float scale, float* out, csm
 int csm_sumsq_blocks(void);
 int csm_sumsq_bf16(const void* g, long long n, float* partials /* [csm_sumsq_blocks()] */, csm_stream_t stream);
 int csm_clip_coef(const float* partials, int n_partials, float max_norm, float* norm_and_coef /* [2] */, csm_stream_t stream);
-int csm_adamw_step(float* master, float* m, float* v, void* param, const void* grad, long long n, float lr, float beta1,
+int csm_adamw_step(float* master, float* m, float* v, void* param, void* grad, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const float* norm_and_coef /* or NULL */,
-                   float grad_mul, csm_stream_t stream);
+                   float grad_mul, int zero_grad /* clear grad in the same pass */, csm_stream_t stream);
 int csm_f32_to_bf16(const float* src, void* dst, long long n, int accumulate, csm_stream_t stream);
 int csm_add_f32_into_bf16(void* a, const float* b, long long n, csm_stream_t stream);
 
