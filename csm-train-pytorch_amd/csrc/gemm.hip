@@ -121,13 +121,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm0 + 16 * i + (lane & 15);
-        if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn0 + 16 * j + 4 * (lane >> 4);
-            if (n >= g.N) continue;
-            epi_store<OutT>(e, vec_ok, m, n, acc[i][j]);
-        }
+        for (int jp = 0; jp < 2; ++jp)
+            epi_store_pair<OutT>(e, vec_ok, m, n0 + wn0 + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
     }
 }
 
@@ -171,9 +167,10 @@ static bool prefer_256(int M, int N, int K, int batch) {
 void csm_gemm256_set_pipelined(int v);
 // 0 register staging, 1 LDS-DMA 128x128, 2 auto (default), 3 force 256x256 (4-quadrant phases), 4 force 256x256 with
 // register-pipelined phases, 5 auto with the 4-quadrant 256 kernel
+// 6 force the persistent-stream 256 kernel, 7 auto with the persistent-stream 256 kernel (measured slower than 2)
 extern "C" int csm_set_gemm_variant(int v) {
-    csm_gemm256_set_pipelined(v == 3 || v == 5 ? 0 : 1);
-    g_gemm_variant = (v == 4) ? 3 : (v == 5 ? 2 : v);
+    csm_gemm256_set_pipelined((v == 3 || v == 5) ? 0 : ((v == 6 || v == 7) ? 2 : 1));
+    g_gemm_variant = (v == 4 || v == 6) ? 3 : ((v == 5 || v == 7) ? 2 : v);
     return 0;
 }
 

@@ -223,4 +223,41 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
     }
 }
 
+// Two horizontally adjacent 16x16 accumulators (columns nb .. nb+31 of the same 16 rows) stored with 16-byte
+// accesses: v_permlane16_swap exchanges the odd 16-lane rows of the left tile with the even rows of the right tile, so
+// even lane-groups end up with 8 consecutive columns of the left tile and odd lane-groups with 8 of the right tile
+// (64 contiguous bytes per output row and instruction, half the store instructions of the 8-byte form - the epilogue
+// of a one-workgroup-per-CU GEMM is store-issue bound).  Falls back to epi_store for fp32 output, fused epilogues,
+// unaligned leading dimensions and column overhang.  All 64 lanes must call this (the swap crosses lanes).
+template <typename OutT>
+__device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m, int nb, int lane, const f32x4& a, const f32x4& b) {
+    const int g = lane >> 4;
+    bool wide = false;
+    if constexpr (sizeof(OutT) == 2)
+        wide = vec_ok && e.mode == EPI_NONE && (e.ldc & 7) == 0 && (!e.R || (e.ldr & 7) == 0) && nb + 31 < e.N &&
+               ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) && (!e.R || (reinterpret_cast<uintptr_t>(e.R) & 15) == 0);
+    if (!wide) {
+        const int n = nb + 4 * g;
+        if (m < e.M && n < e.N) epi_store<OutT>(e, vec_ok, m, n, a);
+        if (m < e.M && n + 16 < e.N) epi_store<OutT>(e, vec_ok, m, n + 16, b);
+        return;
+    }
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[k]), __float_as_uint(b[k]), false, false);
+        v[k] = __uint_as_float(r[0]) * e.alpha;
+        v[4 + k] = __uint_as_float(r[1]) * e.alpha;
+    }
+    if (m >= e.M) return;
+    const int n = nb + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+    if (e.R) {
+        float rr[8];
+        unpack8(*reinterpret_cast<const U4*>(e.R + (size_t)m * e.ldr + n), rr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += rr[k];
+    }
+    *reinterpret_cast<U4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = pack8(v);
+}
+
 }  // namespace
