@@ -446,23 +446,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
                                                     float lr, float beta1, float beta2, float eps, float wd, float bc1,
                                                     float bc2_sqrt, const float* __restrict__ coef_ptr, float gmul,
                                                     int zero_grad) {
-    // every byte is touched exactly once per step: non-temporal loads / stores keep the 44 GB stream out of the caches
-    typedef __attribute__((ext_vector_type(4))) float f4;
+    // plain (default cache policy) 16-byte accesses: measured 5.6 TB/s; non-temporal loads/stores measured 4.5-5.0 TB/s here
     const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gmul;
     const long long nvec = n >> 3;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         float g[8];
-        const U4 gv = __builtin_nontemporal_load(reinterpret_cast<const U4*>(grad + i * 8));
-        unpack8(gv, g);
-        f4 p0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(master + i * 8));
-        f4 p1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(master + i * 8 + 4));
-        f4 m0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m + i * 8));
-        f4 m1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m + i * 8 + 4));
-        f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v + i * 8));
-        f4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v + i * 8 + 4));
-        float p[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-        float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
-        float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        unpack8(*reinterpret_cast<const U4*>(grad + i * 8), g);
+        float4 p0 = *reinterpret_cast<const float4*>(master + i * 8), p1 = *reinterpret_cast<const float4*>(master + i * 8 + 4);
+        float4 m0 = *reinterpret_cast<const float4*>(m + i * 8), m1 = *reinterpret_cast<const float4*>(m + i * 8 + 4);
+        float4 v0 = *reinterpret_cast<const float4*>(v + i * 8), v1 = *reinterpret_cast<const float4*>(v + i * 8 + 4);
+        float p[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gj = g[j] * coef;
@@ -472,13 +467,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
             const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
             p[j] -= (lr / bc1) * (mm[j] / denom);
         }
-        __builtin_nontemporal_store((f4){p[0], p[1], p[2], p[3]}, reinterpret_cast<f4*>(master + i * 8));
-        __builtin_nontemporal_store((f4){p[4], p[5], p[6], p[7]}, reinterpret_cast<f4*>(master + i * 8 + 4));
-        __builtin_nontemporal_store((f4){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f4*>(m + i * 8));
-        __builtin_nontemporal_store((f4){mm[4], mm[5], mm[6], mm[7]}, reinterpret_cast<f4*>(m + i * 8 + 4));
-        __builtin_nontemporal_store((f4){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f4*>(v + i * 8));
-        __builtin_nontemporal_store((f4){vv[4], vv[5], vv[6], vv[7]}, reinterpret_cast<f4*>(v + i * 8 + 4));
-        *reinterpret_cast<U4*>(param + i * 8) = pack8(p);          // the next forward reads these: default policy
+        *reinterpret_cast<float4*>(master + i * 8) = make_float4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<float4*>(master + i * 8 + 4) = make_float4(p[4], p[5], p[6], p[7]);
+        *reinterpret_cast<float4*>(m + i * 8) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<float4*>(m + i * 8 + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+        *reinterpret_cast<float4*>(v + i * 8) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(v + i * 8 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+        *reinterpret_cast<U4*>(param + i * 8) = pack8(p);
         if (zero_grad) *reinterpret_cast<U4*>(grad + i * 8) = (U4){0u, 0u, 0u, 0u};
     }
 }
@@ -685,6 +680,9 @@ extern "C" int csm_clip_coef(const float* partials, int n_partials, float max_no
     return 0;
 }
 
+static int g_adamw_blocks = 16384;
+extern "C" int csm_set_adamw_blocks(int b) { g_adamw_blocks = b; return 0; }
+
 // zero_grad != 0 clears the gradient range in the same pass (the line is already being read)
 extern "C" int csm_adamw_step(float* master, float* m, float* v, void* param, void* grad, long long n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step,
@@ -693,7 +691,7 @@ extern "C" int csm_adamw_step(float* master, float* m, float* v, void* param, vo
     CSM_REQUIRE((n & 7) == 0, "csm_adamw_step: n must be a multiple of 8 (pad the arena)");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 3, 256, 4096)), dim3(256), 0, stream, master, m, v, (bf16_t*)param,
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 3, 256, g_adamw_blocks)), dim3(256), 0, stream, master, m, v, (bf16_t*)param,
                        (bf16_t*)grad, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, norm_and_coef, grad_mul, zero_grad);
     CSM_CHECK_LAUNCH("csm_adamw_step");
     return 0;

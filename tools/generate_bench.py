@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: generate() - AR multi-codebook decode of 10 s of audio (125 frames) on one MI355X, CSM-1B random init.
+The text tokenizer and Mimi cannot be fetched offline: a byte-level stand-in tokenizer and an RVQ-only audio tokenizer
+(random codebooks, csm_rvq_encode / csm_rvq_decode on the GPU) are injected through the Generator constructor."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
+import torch
+from csm.generator import Generator, Segment
+from csm.models.model import Model
+from csm.training.trainer import csm_1b_args
+from csm.hip import ops
+
+
+class ByteTokenizer:
+    def encode(self, text):
+        return [128000] + [b + 1000 for b in text.encode()] + [128001]
+
+
+class RvqOnlyCodec:
+    """Mimi's quantiser stage only: 1920-sample frames are folded into 256-d latents by a fixed random projection."""
+    sample_rate = 24000
+
+    def __init__(self, device, K=32):
+        g = torch.Generator(device=device).manual_seed(0)
+        self.cb = torch.randn(K, 2048, 256, device=device, generator=g)
+        self.proj = torch.randn(1920, 256, device=device, generator=g) / 44.0
+        self.K = K
+
+    def encode(self, wav):                      # [1,1,N] -> [1,K,T]
+        T = wav.shape[-1] // 1920
+        lat = (wav[0, 0, :T * 1920].view(T, 1920) @ self.proj).contiguous()
+        codes = torch.empty(self.K, T, dtype=torch.int64, device=wav.device)
+        ops.rvq_encode(lat, self.cb, codes, 1)
+        return codes.unsqueeze(0)
+
+    def decode(self, codes):                    # [1,K,T] -> [1,1,N]
+        c = codes[0].clamp(0, 2047).contiguous()
+        out = torch.empty(c.shape[1], 256, dtype=torch.float32, device=codes.device)
+        ops.rvq_decode(c, self.cb, out)
+        return (out @ self.proj.t()).reshape(1, 1, -1)
+
+
+def main():
+    dev = "cuda:0"
+    model = Model(csm_1b_args(), device=dev, seed=0)
+    gen = Generator(model, text_tokenizer=ByteTokenizer(), audio_tokenizer=RvqOnlyCodec(dev))
+    ctx = [Segment(0, "hello there", torch.randn(24000, device=dev) * 0.1)]
+    frames = int(os.environ.get("GEN_FRAMES", 125))
+    for n in (5, frames):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        audio = gen.generate("the quick brown fox jumps over the lazy dog", 1, ctx, max_audio_length_ms=80 * n)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(f"{n} frames requested: {audio.numel() / 24000:.2f} s of audio in {dt:.2f} s -> {audio.numel() / 1920 / dt:.1f} frames/s "
+              f"({audio.numel() / 24000 / dt:.2f}x real time)")
+
+
+if __name__ == "__main__":
+    main()
