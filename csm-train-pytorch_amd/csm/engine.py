@@ -385,6 +385,67 @@ class Engine:
 
     @torch.no_grad()
     def generate_frame(self, tokens, tokens_mask, input_pos, temperature, topk, noise=None):
+        """Reference model.py:140-195: backbone position(s) -> c0 -> 31 depth-decoder steps, against KV caches.
+
+        The prompt (``input_pos`` starting at 0) is prefilled with the training forward kernels and its post-RoPE K/V
+        rows are copied into the backbone cache; every later call is a single-position decode step (matrix-vector
+        kernels + cache attention).  The decoder cache is reset every frame, as the reference does (model.py:181).
+        ``model.use_kv_cache = False`` selects the cache-free prefix-recompute path (same arithmetic, kept as a check).
+        """
+        m, a = self.m, self.m.args
+        if not getattr(m, "use_kv_cache", True):
+            return self._generate_frame_recompute(tokens, tokens_mask, input_pos, temperature, topk, noise)
+        dev = m.device
+        K, V, Vp = a.audio_num_codebooks, a.audio_vocab_size, m.vocab_pad
+        d, dd = m.bb.embed_dim, m.dc.embed_dim
+        tokens, tokens_mask = tokens.to(dev), tokens_mask.to(dev)
+        Bn, Sn, K1 = tokens.shape
+        first = int(input_pos[0, 0]) == 0
+        st = getattr(m, "_decode_state", None)
+        if first or st is None or st.B != Bn:
+            st = m._decode_state = DecodeState(self, Bn)
+        if first:
+            last_h = st.prefill(tokens, tokens_mask)
+            return self._frame_tail(st, last_h, temperature, topk, noise)
+        if Sn != 1:
+            raise ValueError("generate_frame with caches: after the prompt, feed one position per call")
+        if noise is None and getattr(m, "use_hip_graph", True):
+            return st.graph_frame(tokens, tokens_mask, temperature, topk)
+        st.cur += 1
+        return self._decode_frame(st, tokens, tokens_mask, temperature, topk, noise)
+
+    def _decode_frame(self, st, tokens, tokens_mask, temperature, topk, noise):
+        """One decode frame with no host-side dependence on device data: this is the body a HIP graph captures."""
+        last_h = st.backbone_step(tokens, tokens_mask)
+        return self._frame_tail(st, last_h, temperature, topk, noise)
+
+    def _frame_tail(self, st, last_h, temperature, topk, noise):
+        m, a = self.m, self.m.args
+        dev = m.device
+        K, V = a.audio_num_codebooks, a.audio_vocab_size
+        from .models.model import sample_topk
+
+        def draw(lg, i):
+            q = None if noise is None else noise[i].to(dev)
+            return sample_topk(lg[:, :V], topk, temperature, q)
+
+        ops.gemv(last_h, m.block("codebook0_head.padded"), st.logits)
+        c0 = draw(st.logits, 0)
+        samples = [c0]
+        aemb = m.block("audio_embeddings.weight")
+        x_in = last_h
+        for i in range(K):
+            # decoder position i: input = backbone state (i = 0) or the embedding of code i-1
+            hdec = st.decoder_step(x_in, i)
+            if i >= 1:
+                ops.gemv(hdec, st.head_t[i - 1], st.logits)      # [V][d'] copy of audio_head[i-1]: row-per-wave GEMV
+                samples.append(draw(st.logits, i))
+            if i < K - 1:
+                x_in = aemb[samples[-1].long().view(-1) + i * V]
+        return torch.cat(samples, dim=1)
+
+    @torch.no_grad()
+    def _generate_frame_recompute(self, tokens, tokens_mask, input_pos, temperature, topk, noise=None):
         """Reference model.py:140-195.  The KV state is the token history (prefix recompute)."""
         m, a = self.m, self.m.args
         dev = m.device
@@ -427,3 +488,134 @@ class Engine:
             samples.append(ci)
             seq.append(aemb[ci.long() + i * V])
         return torch.cat(samples, dim=1)
+
+
+class _DecodeStack:
+    """KV caches + preallocated single-position buffers of one stack."""
+
+    def __init__(self, stack: _Stack, B: int, s_max: int):
+        c, dev = stack.c, stack.m.device
+        self.stack, self.B, self.s_max = stack, B, s_max
+        H, KV, hd, F, d = c.num_heads, c.num_kv_heads, c.head_dim, c.intermediate_dim, c.embed_dim
+        z = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)   # noqa: E731
+        self.k = [torch.zeros(B, KV, s_max, hd, dtype=BF16, device=dev) for _ in range(c.num_layers)]
+        self.v = [torch.zeros(B, KV, s_max, hd, dtype=BF16, device=dev) for _ in range(c.num_layers)]
+        self.pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.xn, self.qkv, self.o, self.h, self.hn = z(B, d), z(B, c.qkv_dim), z(B, H * hd), z(B, d), z(B, d)
+        self.gu, self.act, self.xa, self.xb, self.xf = z(B, 2 * F), z(B, F), z(B, d), z(B, d), z(B, d)
+
+    def fill_from(self, acts, B, S):
+        """Copy the post-RoPE K / V rows of a prefilled prompt into the caches."""
+        c = self.stack.c
+        H, KV, hd = c.num_heads, c.num_kv_heads, c.head_dim
+        for i, a in enumerate(acts):
+            qkv = a["qkv"].view(B, S, -1)
+            self.k[i][:, :, :S] = qkv[:, :, H * hd:(H + KV) * hd].reshape(B, S, KV, hd).permute(0, 2, 1, 3)
+            self.v[i][:, :, :S] = qkv[:, :, (H + KV) * hd:].reshape(B, S, KV, hd).permute(0, 2, 1, 3)
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        """One position per batch row at ``self.pos`` (device int32).  x [B, d] -> final-normed hidden [B, d]."""
+        st, c = self.stack, self.stack.c
+        H, KV, hd = c.num_heads, c.num_kv_heads, c.head_dim
+        table = st.m.rope_table(st.prefix)
+        cur, nxt = x, self.xa
+        for i in range(c.num_layers):
+            ops.rmsnorm_fwd(cur, st.w(f"layers.{i}.sa_norm.scale"), self.xn, None, c.norm_eps)
+            ops.gemv(self.xn, st.w(f"layers.{i}.attn.qkv"), self.qkv)
+            ops.rope(self.qkv, table, 1, H + KV, hd, pos=self.pos)
+            ops.kv_append(self.qkv, self.k[i], self.v[i], self.pos, H, KV, hd)
+            ops.attn_decode(self.qkv, self.k[i], self.v[i], self.o, self.pos, H, KV, hd)
+            ops.gemv(self.o, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, residual=cur)
+            ops.rmsnorm_fwd(self.h, st.w(f"layers.{i}.mlp_norm.scale"), self.hn, None, c.norm_eps)
+            ops.gemv(self.hn, st.w(f"layers.{i}.mlp.w13"), self.gu)
+            ops.swiglu_fwd(self.gu, self.act)
+            ops.gemv(self.act, st.w(f"layers.{i}.mlp.w2.weight"), nxt, residual=self.h)
+            cur, nxt = nxt, (self.xb if nxt is self.xa else self.xa)
+        ops.rmsnorm_fwd(cur, st.w("norm.scale"), self.xf, None, c.norm_eps)
+        return self.xf
+
+
+class DecodeState:
+    """Everything ``generate_frame`` keeps between calls: the two stacks' caches and small persistent buffers."""
+
+    def __init__(self, engine: "Engine", B: int):
+        m = engine.m
+        if m.lora is not None:
+            raise NotImplementedError("generate with un-merged LoRA adapters: call model.merge_lora_weights() first")
+        if B > 4:
+            raise ValueError("the decode kernels handle up to 4 sequences at a time")
+        self.e, self.B = engine, B
+        dev = m.device
+        self.bb = _DecodeStack(engine.backbone, B, m.bb.max_seq_len)
+        self.dc = _DecodeStack(engine.decoder, B, m.args.audio_num_codebooks)
+        self.h0 = torch.empty(B, m.bb.embed_dim, dtype=BF16, device=dev)
+        self.proj = torch.empty(B, m.dc.embed_dim, dtype=BF16, device=dev)
+        self.logits = torch.empty(B, m.vocab_pad, dtype=F32, device=dev)
+        self.dpos = [torch.full((B,), i, dtype=torch.int32, device=dev) for i in range(m.args.audio_num_codebooks)]
+        self.cur = -1
+        self.graph, self.graph_key, self.warm = None, None, 0
+        # audio_head is stored [K-1][d'][V] (reference layout, a K-major matrix for x @ W); the decode path wants one
+        # output row per wave, so it keeps a [K-1][V][d'] copy made from the current weights when the state is created
+        self.head_t = m.block("audio_head.padded").transpose(1, 2).contiguous()
+
+    def prefill(self, tokens, masks):
+        e, m = self.e, self.e.m
+        B, S, K1 = tokens.shape
+        if S > m.bb.max_seq_len:
+            raise ValueError("prompt longer than max_seq_len")
+        M = B * S
+        tk = tokens.reshape(M, K1).to(torch.int64).contiguous()
+        mk = masks.reshape(M, K1).to(torch.uint8).contiguous()
+        h0 = torch.empty(M, m.bb.embed_dim, dtype=BF16, device=m.device)
+        ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, m.args.audio_vocab_size)
+        hidden = e.backbone.forward(h0, B, S, True)
+        self.bb.fill_from(e.backbone.acts, B, S)
+        e.backbone.acts = []
+        self.bb.pos.fill_(S - 1)
+        self.cur = S - 1                       # host mirror of the device-side position (no sync per frame)
+        return hidden.view(B, S, -1)[:, -1, :].contiguous()
+
+    def backbone_step(self, tokens, masks):
+        m = self.e.m
+        B = tokens.shape[0]
+        tk = tokens.reshape(B, -1).to(torch.int64).contiguous()
+        mk = masks.reshape(B, -1).to(torch.uint8).contiguous()
+        ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), self.h0, m.args.audio_vocab_size)
+        self.bb.pos.add_(1)
+        return self.bb.step(self.h0)
+
+    def graph_frame(self, tokens, masks, temperature, topk):
+        """Replay one decode frame (~1.8 k kernel launches) as a single HIP graph.  The first decode frame runs eagerly
+        (warm-up: lazy function attributes, allocator), the second is captured, later ones are replays; positions live in
+        device memory, so the same graph serves every frame.  Re-captured when temperature / top-k change."""
+        m = self.e.m
+        if self.cur + 1 >= m.bb.max_seq_len:
+            raise ValueError("sequence exceeds max_seq_len")
+        self.cur += 1
+        key = (float(temperature), int(topk))
+        if self.graph is None or self.graph_key != key:
+            if self.warm < 1 or self.graph_key not in (None, key):
+                self.warm, self.graph, self.graph_key = 1, None, None
+                return self.e._decode_frame(self, tokens, masks, temperature, topk, None)
+            self.in_tok = tokens.to(torch.int64).clone()
+            self.in_msk = masks.to(torch.uint8).clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.out_static = self.e._decode_frame(self, self.in_tok, self.in_msk, temperature, topk, None)
+            self.graph, self.graph_key = g, key
+            g.replay()
+            return self.out_static.clone()
+        self.in_tok.copy_(tokens)
+        self.in_msk.copy_(masks)
+        self.graph.replay()
+        return self.out_static.clone()
+
+    def decoder_reset(self):
+        pass   # positions restart at 0 every frame; stale cache rows beyond the current position are never read
+
+    def decoder_step(self, x_in, i):
+        m = self.e.m
+        ops.gemv(x_in.contiguous(), m.block("projection.weight"), self.proj)
+        self.dc.pos = self.dpos[i]
+        return self.dc.step(self.proj)

@@ -55,6 +55,11 @@ _SIGS = {
     "csm_adamw_step": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _i, _p], _i),
     "csm_f32_to_bf16": ([_p, _p, _ll, _i, _p], _i),
     "csm_add_f32_into_bf16": ([_p, _p, _ll, _p], _i),
+    "csm_set_adamw_blocks": ([_i], _i),
+    "csm_gemv_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "csm_gemv_t_bf16": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "csm_kv_append": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "csm_attn_decode": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_sample_topk": ([_p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "csm_rvq_encode": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_rvq_decode": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),

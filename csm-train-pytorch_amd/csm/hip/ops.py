@@ -208,6 +208,39 @@ def add_f32_into_bf16(a, b):
     check(lib.csm_add_f32_into_bf16(a.data_ptr(), b.data_ptr(), a.numel(), _stream()), "csm_add_f32_into_bf16")
 
 
+def gemv(x, W, y, residual=None):
+    """y[B,N] = x[B,K] W[N,K]^T (+ residual), B <= 4."""
+    B, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and y.shape == (B, N) and x.stride(1) == 1 and W.stride(1) == 1 and y.stride(1) == 1
+    check(lib.csm_gemv_bf16(x.data_ptr(), W.data_ptr(), y.data_ptr(), _ptr(residual), B, N, K, W.stride(0), x.stride(0),
+                            y.stride(0), int(y.dtype == torch.float32), _stream()), "csm_gemv_bf16")
+    return y
+
+
+def gemv_t(x, W, y):
+    """y[B,N] = x[B,K] W[K,N], B <= 4."""
+    B, K = x.shape
+    N = W.shape[1]
+    assert W.shape[0] == K and y.shape == (B, N) and W.stride(1) == 1
+    check(lib.csm_gemv_t_bf16(x.data_ptr(), W.data_ptr(), y.data_ptr(), B, N, K, W.stride(0), x.stride(0), y.stride(0),
+                              int(y.dtype == torch.float32), _stream()), "csm_gemv_t_bf16")
+    return y
+
+
+def kv_append(qkv, kcache, vcache, pos_i32, H, KV, HD):
+    B, _, S_max, _ = kcache.shape
+    check(lib.csm_kv_append(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), pos_i32.data_ptr(), B, H, KV, HD, S_max,
+                            qkv.stride(0), _stream()), "csm_kv_append")
+
+
+def attn_decode(qkv, kcache, vcache, out, pos_i32, H, KV, HD):
+    B, _, S_max, _ = kcache.shape
+    check(lib.csm_attn_decode(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), pos_i32.data_ptr(), B, H, KV,
+                              HD, S_max, qkv.stride(0), _stream()), "csm_attn_decode")
+    return out
+
+
 def sample_topk(logits_f32, q_f32, out_i32, topk, temperature, V=None):
     rows = logits_f32.shape[0]
     V = V or logits_f32.shape[1]

@@ -164,6 +164,8 @@ class Model(nn.Module):
         self._engine = None
         self._init_seed = seed
         self._fp32_source = None
+        self.use_kv_cache = True                              # generate_frame: KV caches (False = prefix recompute)
+        self.use_hip_graph = True                             # replay decode frames as one captured HIP graph
         # which parameter groups receive weight gradients (freeze flags of trainer.prepare_optimizer / LoRA)
         self.trainable = {"backbone": True, "decoder": True, "embeddings": True, "other": True}
         if device is not None:
@@ -366,18 +368,20 @@ class Model(nn.Module):
     # ------------------------------------------------------------------ reference API
     def setup_caches(self, max_batch_size: int) -> None:
         """Reference model.py:128-138.  Registers the two causal-mask buffers for API parity; the KV state of
-        ``generate_frame`` is kept by the engine (prefix recompute in this round)."""
+        ``generate_frame`` (KV caches of both stacks) is kept by the engine's ``DecodeState``."""
         dev = self._device
         self._max_batch = max_batch_size
         self.register_buffer("backbone_causal_mask", _create_causal_mask(self.bb.max_seq_len, dev), persistent=False)
         self.register_buffer("decoder_causal_mask", _create_causal_mask(self.args.audio_num_codebooks, dev), persistent=False)
         self._gen_hist = None
+        self._decode_state = None
 
     def caches_are_enabled(self) -> bool:
         return hasattr(self, "backbone_causal_mask")
 
     def reset_caches(self):
         self._gen_hist = None
+        self._decode_state = None
 
     def _embed_audio(self, codebook: int, tokens: torch.Tensor) -> torch.Tensor:
         """Reference model.py:202-204 (a plain row gather: indexing, no arithmetic)."""

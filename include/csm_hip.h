@@ -115,12 +115,27 @@ int csm_clip_coef(const float* partials, int n_partials, float max_norm, float* 
 int csm_adamw_step(float* master, float* m, float* v, void* param, void* grad, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const float* norm_and_coef /* or NULL */,
                    float grad_mul, int zero_grad /* clear grad in the same pass */, csm_stream_t stream);
+int csm_set_adamw_blocks(int blocks); /* tuning switch */
 int csm_f32_to_bf16(const float* src, void* dst, long long n, int accumulate, csm_stream_t stream);
 int csm_add_f32_into_bf16(void* a, const float* b, long long n, csm_stream_t stream);
 
 /* ---- K14: sample_topk + _multinomial_sample_one_no_sync (model.py:79-96), Exp(1) noise q supplied ---------------- */
 int csm_sample_topk(const float* logits, const float* q, int* out, int rows, int V, int ldl, int topk, float temperature,
                     csm_stream_t stream);
+
+/* ---- K15: batch-1 decode of Model.generate_frame (model.py:161-195) against KV caches ------------------------------ *
+ * y[b][n] = sum_k x[b][k] W[n][k] (+ residual[b][n]), B <= 4 (weight-streaming matrix-vector product) */
+int csm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
+                  int out_f32, csm_stream_t stream);
+/* y[b][n] = sum_k x[b][k] W[k][n]  (K-major weights: audio_head[i] = [decoder_dim][vocab]) */
+int csm_gemv_t_bf16(const void* x, const void* W, void* y, int B, int N, int K, int ldw, int ldx, int ldy, int out_f32,
+                    csm_stream_t stream);
+/* caches are [B][KV][S_max][HD] bf16; pos = int32 [B] on the device (graph-replayable): the new key/value row index */
+int csm_kv_append(const void* qkv, void* kcache, void* vcache, const int* pos, int B, int H, int KV, int HD, int S_max, int ld,
+                  csm_stream_t stream);
+/* out[b][h*HD..] = softmax(q . K[0..pos[b]]^T / sqrt(HD)) V   for the single query row in qkv[b] */
+int csm_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* out, const int* pos, int B, int H, int KV,
+                    int HD, int S_max, int ld, csm_stream_t stream);
 
 /* ---- K16 (RVQ part): Mimi split residual VQ behind generator.py:117,209 ------------------------------------------ */
 int csm_rvq_encode(const float* x, const float* codebooks, long long* codes, int T, int K, int C, int D, int n_semantic,

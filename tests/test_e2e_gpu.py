@@ -209,6 +209,100 @@ def test_generate_frame_matches_reference_fixture(dev):
     assert got == meta["generate_frames"], (got, meta["generate_frames"])
 
 
+def test_generate_kv_cache_vs_recompute_and_graph(dev):
+    """KV-cache decode path vs the cache-free recompute path on the SAME history and noise: the two use different
+    reduction orders (matrix-vector kernels vs MFMA tiles), so a rare near-tie may sample differently; they must agree
+    on almost every code.  The captured-graph replay must reproduce the eager KV path exactly (same kernels)."""
+    m, _, _ = tiny_model(dev)
+    K = TINY.n_codebooks
+    tokens, mask, _ = O.synthetic_batch(TINY, 2, 20, seed=12)
+
+    def noise(step):
+        g = torch.Generator().manual_seed(500 + step)
+        return [torch.empty(2, TINY.audio_vocab).exponential_(1, generator=g) for _ in range(K)]
+
+    def run(use_cache, history):
+        m.use_kv_cache = use_cache
+        m.setup_caches(2)
+        m.reset_caches()
+        cur_t, cur_m, cur_p = tokens[:, :11], mask[:, :11], torch.arange(11).unsqueeze(0).repeat(2, 1)
+        frames = []
+        for step in range(8):
+            f = m.generate_frame(cur_t, cur_m, cur_p, 0.8, 12, noise=noise(step)).cpu()
+            frames.append(f)
+            nxt = history[step] if history is not None else f            # teacher-force the reference history
+            cur_t = torch.cat([nxt.long(), torch.zeros(2, 1, dtype=torch.long)], dim=1).unsqueeze(1)
+            cur_m = torch.cat([torch.ones(2, K, dtype=torch.bool), torch.zeros(2, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
+            cur_p = cur_p[:, -1:] + 1
+        return torch.stack(frames)
+
+    kv = run(True, None)
+    rc = run(False, kv)
+    m.use_kv_cache = True
+    agree = (kv == rc).float().mean().item()
+    assert agree >= 0.9, f"KV-cache and recompute paths agree on only {agree:.1%} of the sampled codes"
+    assert torch.equal(kv[0], rc[0]), "the prefill frame goes through the same kernels in both paths"
+    # graph replay == eager decode, with torch's own generator seeded identically
+    outs = []
+    for use_graph in (False, True):
+        m.use_hip_graph = use_graph
+        m.setup_caches(2)
+        m.reset_caches()
+        torch.manual_seed(1234)
+        torch.cuda.manual_seed(1234)
+        cur_t, cur_m, cur_p = tokens[:, :11], mask[:, :11], torch.arange(11).unsqueeze(0).repeat(2, 1)
+        frames = []
+        for step in range(6):
+            f = m.generate_frame(cur_t, cur_m, cur_p, 0.8, 12).cpu()
+            frames.append(f)
+            cur_t = torch.cat([f.long(), torch.zeros(2, 1, dtype=torch.long)], dim=1).unsqueeze(1)
+            cur_m = torch.cat([torch.ones(2, K, dtype=torch.bool), torch.zeros(2, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
+            cur_p = cur_p[:, -1:] + 1
+        outs.append(torch.stack(frames))
+    m.use_hip_graph = True
+    assert outs[0].shape == outs[1].shape == (6, 2, K)
+    assert torch.equal(outs[0][:2], outs[1][:2]), "prefill + eager warm-up frame are identical code paths"
+    assert int(outs[1].min()) >= 0 and int(outs[1].max()) < TINY.audio_vocab
+
+
+def test_decode_kernels_vs_oracle(dev):
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(44)
+    # gemv / gemv_t
+    x, W = (torch.randn(3, 1024, generator=g)).to(BF), (torch.randn(300, 1024, generator=g) * 0.1).to(BF)
+    R = torch.randn(3, 300, generator=g).to(BF)
+    y = torch.empty(3, 300, dtype=BF, device=dev)
+    ops.gemv(x.to(dev), W.to(dev), y, residual=R.to(dev))
+    gclose("gemv", y, x.float() @ W.float().t() + R.float(), 1e-2)
+    Wt = (torch.randn(512, 2112, generator=g) * 0.1).to(BF)
+    x2 = torch.randn(2, 512, generator=g).to(BF)
+    y2 = torch.empty(2, 2112, dtype=torch.float32, device=dev)
+    ops.gemv_t(x2.to(dev), Wt.to(dev), y2)
+    gclose("gemv_t", y2, x2.float() @ Wt.float(), 1e-4)
+    # cache attention for both head dims, ragged positions per batch row
+    for H, KV, hd in ((4, 2, 64), (2, 1, 128)):
+        B, S_max = 2, 96
+        qkv = torch.randn(B, (H + 2 * KV) * hd, generator=g).to(BF)
+        kc = torch.randn(B, KV, S_max, hd, generator=g).to(BF)
+        vc = torch.randn(B, KV, S_max, hd, generator=g).to(BF)
+        pos = torch.tensor([70, 13], dtype=torch.int32)
+        kd, vd = kc.to(dev), vc.to(dev)
+        ops.kv_append(qkv.to(dev), kd, vd, pos.to(dev), H, KV, hd)
+        out = torch.empty(B, H * hd, dtype=BF, device=dev)
+        ops.attn_decode(qkv.to(dev), kd, vd, out, pos.to(dev), H, KV, hd)
+        for b in range(B):
+            n = int(pos[b]) + 1
+            kk, vv = kc[b].clone().float(), vc[b].clone().float()
+            kk[:, n - 1] = qkv[b, H * hd:(H + KV) * hd].view(KV, hd).float()
+            vv[:, n - 1] = qkv[b, (H + KV) * hd:].view(KV, hd).float()
+            assert torch.equal(kd[b, :, n - 1].cpu().float(), kk[:, n - 1])
+            q = qkv[b, :H * hd].view(H, hd).float()
+            for h in range(H):
+                kvh = h // (H // KV)
+                p = torch.softmax(kk[kvh, :n] @ q[h] / hd ** 0.5, dim=0)
+                gclose(f"attn_decode b{b} h{h}", out[b, h * hd:(h + 1) * hd], p @ vv[kvh, :n], 1.5e-2)
+
+
 def test_checkpoint_roundtrip(dev, tmp_path):
     from csm.training.optim import FusedAdamW
     from csm.training.utils import compute_loss, load_checkpoint, save_checkpoint
