@@ -72,8 +72,33 @@ def linear_dx(dy, w, out, residual=None, alpha=1.0):
     return gemm(dy, w, out, residual, False, True, alpha)
 
 
+_splitk_ws = {}
+
+
 def linear_dw(dy, x, out, accumulate=False, alpha=1.0):
-    """out[N,K] (+)= dy[M,N]^T x[M,K]."""
+    """out[N,K] (+)= dy[M,N]^T x[M,K].
+
+    Weight gradients with a small output and a long contraction (attention output projection, every decoder matrix)
+    would put a handful of 256x256 tiles on 256 CUs; those are split along the contraction over the GEMM's batch
+    dimension into fp32 partial slabs (so that tiles x splits fills the chip) and summed into the bf16 gradient by the
+    column-sum kernel."""
+    Mrows, N = dy.shape
+    Kout = x.shape[1]
+    tiles = ((N + 255) // 256) * ((Kout + 255) // 256)
+    if tiles <= 96 and Mrows >= 4096 and out.is_contiguous() and Mrows % 64 == 0:
+        splits = 1
+        while tiles * splits * 2 <= 256 and (Mrows // (splits * 2)) % 64 == 0 and Mrows // (splits * 2) >= 512:
+            splits *= 2
+        if splits > 1:
+            chunk = Mrows // splits
+            key = (splits, N, Kout, dy.device)
+            ws = _splitk_ws.get(key)
+            if ws is None:
+                ws = _splitk_ws[key] = torch.empty(splits, N * Kout, dtype=torch.float32, device=dy.device)
+            gemm(dy[:chunk], x[:chunk], ws[0].view(N, Kout), None, True, True, alpha, batch=splits,
+                 sA=chunk * dy.stride(0), sB=chunk * x.stride(0), sC=N * Kout)
+            colsum_bf16(ws, out.view(-1), accumulate=accumulate)
+            return out
     return gemm(dy, x, out, out if accumulate else None, True, True, alpha)
 
 
