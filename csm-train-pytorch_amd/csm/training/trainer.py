@@ -102,8 +102,18 @@ class CSMTrainer:
     def train(self, train_dataset, val_dataset=None, batch_size: int = 2, accumulation_steps: int = 4, epochs: int = 5,
               val_every: int = 100, save_every: int = 500, max_grad_norm: float = 1.0, resume_from: Optional[str] = None):
         """Reference trainer.py:175-357."""
-        train_loader = create_dataloader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=2)
-        val_loader = create_dataloader(val_dataset, batch_size=batch_size, shuffle=False, num_workers=2) if val_dataset else None
+        nw = getattr(self, "num_workers", 2)
+        if GradSync.active():
+            # data parallel: every rank walks its own shard of the dataset (new capability, see training/dp.py)
+            from torch.utils.data import DataLoader
+            from torch.utils.data.distributed import DistributedSampler
+            from ..data import collate_variable_length
+            sampler = DistributedSampler(train_dataset, shuffle=True, drop_last=True)
+            train_loader = DataLoader(train_dataset, batch_size=batch_size, sampler=sampler, num_workers=nw,
+                                      collate_fn=collate_variable_length, pin_memory=True, drop_last=True)
+        else:
+            train_loader = create_dataloader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=nw)
+        val_loader = create_dataloader(val_dataset, batch_size=batch_size, shuffle=False, num_workers=nw) if val_dataset else None
         if self.optimizer is None:
             self.prepare_optimizer()
         if resume_from:

@@ -322,3 +322,20 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert meta["epoch"] == 1 and meta["global_step"] == 7
     assert torch.equal(m2.arena, m.arena)
     assert torch.equal(opt2.state["backbone"]["m"], opt.state["backbone"]["m"])
+
+
+def test_cli_entry_points(dev, tmp_path, monkeypatch):
+    """csm-train / csm-finetune-lora front ends: reference flag names, tiny model, synthetic data, one epoch."""
+    import csm.training.trainer as T
+    from csm.models.model import ModelArgs
+    monkeypatch.setattr(T, "csm_1b_args", lambda: ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", 128256, 2051, 32))
+    from csm.cli import train as cli_train, finetune_lora as cli_lora
+    rc = cli_train.main(["--model-path", "", "--output-dir", str(tmp_path / "t"), "--synthetic", "6", "--max-seq-len", "48",
+                         "--epochs", "1", "--batch-size", "2", "--accumulation-steps", "1", "--num-workers", "0",
+                         "--acoustic-mode", "amortized", "--val-every", "1", "--freeze-embeddings"])
+    assert rc == 0 and (tmp_path / "t" / "final_latest.pt").exists()
+    rc = cli_lora.main(["--model-path", "", "--output-dir", str(tmp_path / "l"), "--synthetic", "6", "--max-seq-len", "48",
+                        "--epochs", "1", "--batch-size", "2", "--lora-r", "8", "--target-modules", "q_proj", "v_proj", "--save-mode", "both"])
+    assert rc == 0 and (tmp_path / "l" / "final_lora.safetensors").exists() and (tmp_path / "l" / "final_full.safetensors").exists()
+    meta = json.load(open(tmp_path / "l" / "final_lora_metadata.json"))
+    assert meta["lora_r"] == 8 and meta["target_modules"] == ["q_proj", "v_proj"]
