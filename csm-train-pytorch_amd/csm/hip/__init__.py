@@ -42,19 +42,15 @@ _SIGS = {
     "csm_swiglu_fwd": ([_p, _p, _ll, _i, _p], _i),
     "csm_swiglu_bwd": ([_p, _p, _p, _ll, _i, _p], _i),
     "csm_embed_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
-    "csm_embed_bwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
     "csm_embed_bwd_sorted": ([_p, _p, _ll, _p, _p, _ll, _p, _p, _ll, _ll, _i, _p], _i),
     "csm_rows_add_bf16": ([_p, _p, _p, _ll, _i, _i, _p], _i),
     "csm_decoder_input_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
-    "csm_decoder_input_bwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
     "csm_ce_fwd_bwd": ([_p, _p, _p, _p, _ll, _i, _i, _i, _f, _p], _i),
     "csm_reduce_sum_f32": ([_p, _ll, _f, _p, _p], _i),
     "csm_sumsq_blocks": ([], _i),
     "csm_sumsq_bf16": ([_p, _ll, _p, _p], _i),
     "csm_clip_coef": ([_p, _i, _f, _p, _p], _i),
     "csm_adamw_step": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _i, _p], _i),
-    "csm_f32_to_bf16": ([_p, _p, _ll, _i, _p], _i),
-    "csm_add_f32_into_bf16": ([_p, _p, _ll, _p], _i),
     "csm_set_adamw_blocks": ([_i], _i),
     "csm_gemv_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_gemv_t_bf16": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),

@@ -161,12 +161,6 @@ def embed_fwd(tokens, mask_u8, text_emb, audio_emb, out, audio_vocab):
     return out
 
 
-def embed_bwd(tokens, mask_u8, dh, d_text_f32, d_audio_f32, audio_vocab):
-    M, K1 = tokens.shape
-    check(lib.csm_embed_bwd(tokens.data_ptr(), mask_u8.data_ptr(), dh.data_ptr(), d_text_f32.data_ptr(),
-                            d_audio_f32.data_ptr(), M, K1 - 1, dh.shape[1], audio_vocab, _stream()), "csm_embed_bwd")
-
-
 def embed_bwd_sorted(sorted_rows, src_index, dh, dseq, g_text, g_audio):
     assert sorted_rows.dtype == torch.int64 and src_index.dtype == torch.int64 and sorted_rows.is_contiguous() and src_index.is_contiguous()
     check(lib.csm_embed_bwd_sorted(sorted_rows.data_ptr(), src_index.data_ptr(), sorted_rows.numel(), dh.data_ptr(), _ptr(dseq),
@@ -185,13 +179,6 @@ def decoder_input_fwd(hidden, rows_i32, codes, audio_emb, out, audio_vocab):
     check(lib.csm_decoder_input_fwd(hidden.data_ptr(), rows_i32.data_ptr(), codes.data_ptr(), audio_emb.data_ptr(),
                                     out.data_ptr(), N, K, hidden.shape[1], audio_vocab, _stream()), "csm_decoder_input_fwd")
     return out
-
-
-def decoder_input_bwd(dseq, rows_i32, codes, d_hidden_f32, d_audio_f32, audio_vocab):
-    N, K = codes.shape
-    check(lib.csm_decoder_input_bwd(dseq.data_ptr(), rows_i32.data_ptr(), codes.data_ptr(), d_hidden_f32.data_ptr(),
-                                    _ptr(d_audio_f32), N, K, d_hidden_f32.shape[1], audio_vocab, _stream()),
-          "csm_decoder_input_bwd")
 
 
 def ce_fwd_bwd(logits_f32, targets, loss_rows, dlogits, V, grad_scale):
@@ -223,14 +210,6 @@ def adamw_step(master, m, v, param, grad, lr, beta1, beta2, eps, wd, step, norm_
     assert master.dtype == torch.float32 and param.dtype == BF16 and grad.dtype == BF16 and param.numel() == n == grad.numel()
     check(lib.csm_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), param.data_ptr(), grad.data_ptr(), n, lr, beta1,
                              beta2, eps, wd, int(step), _ptr(norm_and_coef), float(grad_mul), int(zero_grad), _stream()), "csm_adamw_step")
-
-
-def f32_to_bf16(src, dst, accumulate=False):
-    check(lib.csm_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), int(accumulate), _stream()), "csm_f32_to_bf16")
-
-
-def add_f32_into_bf16(a, b):
-    check(lib.csm_add_f32_into_bf16(a.data_ptr(), b.data_ptr(), a.numel(), _stream()), "csm_add_f32_into_bf16")
 
 
 def gemv(x, W, y, residual=None):

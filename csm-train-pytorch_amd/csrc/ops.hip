@@ -250,24 +250,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
     }
 }
 
-// scatter-add of dh rows into fp32 embedding-gradient scratch; lane l adds column l + 64*j: 256 contiguous
-// bytes per wave-instruction, the shape global float atomics run fastest at.
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tokens, const uint8_t* __restrict__ mask,
-                                                        const bf16_t* __restrict__ dh, float* __restrict__ d_text,
-                                                        float* __restrict__ d_audio, int K, int D, int audio_vocab) {
-    const long long row = blockIdx.x;
-    const long long* tok = tokens + row * (K + 1);
-    const uint8_t* mk = mask + row * (K + 1);
-    for (int col = threadIdx.x; col < D; col += blockDim.x) {
-        const float g = bf2f(dh[(size_t)row * D + col]);
-        for (int s = 0; s <= K; ++s) {
-            if (!mk[s]) continue;
-            float* dst = (s < K) ? d_audio + ((size_t)tok[s] + (size_t)s * audio_vocab) * D : d_text + (size_t)tok[s] * D;
-            atomicAdd(dst + col, g);
-        }
-    }
-}
-
 // Deterministic, scratch-free embedding backward: the (row, source) occurrence list is sorted by embedding row on the
 // host side (torch.sort, no sync); one wave per occurrence index, only the FIRST occurrence of a row does work: it sums
 // the bf16 gradient rows of every occurrence of that row in fp32 registers (fixed order) and adds the result into the
@@ -348,18 +330,6 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const bf16_t* __rest
                                  : audio_emb + ((size_t)codes[n * K + i - 1] + (size_t)(i - 1) * audio_vocab) * D;
     for (int c0 = threadIdx.x * 8; c0 < D; c0 += blockDim.x * 8)
         *reinterpret_cast<U4*>(out + ((size_t)n * K + i) * D + c0) = *reinterpret_cast<const U4*>(src + c0);
-}
-
-// backward of the above: position 0 -> atomically into fp32 d_hidden scratch rows, positions >=1 -> fp32 d_audio rows
-__global__ __launch_bounds__(256) void decoder_input_bwd_kernel(const bf16_t* __restrict__ dseq, const int* __restrict__ rows,
-                                                                const long long* __restrict__ codes, float* __restrict__ d_hidden,
-                                                                float* __restrict__ d_audio, int K, int D, int audio_vocab) {
-    const long long n = blockIdx.x / K;
-    const int i = blockIdx.x % K;
-    float* dst = (i == 0) ? d_hidden + (size_t)rows[n] * D
-                          : (d_audio ? d_audio + ((size_t)codes[n * K + i - 1] + (size_t)(i - 1) * audio_vocab) * D : nullptr);
-    if (!dst) return;
-    for (int col = threadIdx.x; col < D; col += blockDim.x) atomicAdd(dst + col, bf2f(dseq[((size_t)n * K + i) * D + col]));
 }
 
 // ------------------------------------------------------------------------------------------------ cross-entropy
@@ -478,35 +448,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     }
 }
 
-// dst(bf16) = (accumulate ? dst : 0) + src(fp32)   (embedding / norm-scale gradient scratch -> bf16 gradient arena)
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n,
-                                                          int accumulate) {
-    const long long nvec = n >> 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
-        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        if (accumulate) {
-            float o[8];
-            unpack8(*reinterpret_cast<const U4*>(dst + i * 8), o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] += o[j];
-        }
-        *reinterpret_cast<U4*>(dst + i * 8) = pack8(f);
-    }
-}
-
-// out(bf16) = a(bf16) + b(fp32)  (adds the decoder's fp32 d_hidden scratch into the backbone's output gradient)
-__global__ __launch_bounds__(256) void add_f32_kernel(bf16_t* __restrict__ a, const float* __restrict__ b, long long n) {
-    const long long nvec = n >> 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const float4 x = *reinterpret_cast<const float4*>(b + i * 8), y = *reinterpret_cast<const float4*>(b + i * 8 + 4);
-        float f[8];
-        unpack8(*reinterpret_cast<const U4*>(a + i * 8), f);
-        f[0] += x.x; f[1] += x.y; f[2] += x.z; f[3] += x.w; f[4] += y.x; f[5] += y.y; f[6] += y.z; f[7] += y.w;
-        *reinterpret_cast<U4*>(a + i * 8) = pack8(f);
-    }
-}
-
 inline int grid_for(long long work_items, int block, int cap = 256 * 8) {
     long long b = (work_items + block - 1) / block;
     if (b < 1) b = 1;
@@ -591,16 +532,6 @@ extern "C" int csm_embed_fwd(const long long* tokens, const uint8_t* mask, const
     return 0;
 }
 
-extern "C" int csm_embed_bwd(const long long* tokens, const uint8_t* mask, const void* dh, float* d_text, float* d_audio,
-                             long long M, int K, int D, int audio_vocab, hipStream_t stream) {
-    CSM_REQUIRE(tokens && mask && dh && d_text && d_audio, "csm_embed_bwd: null pointer");
-    CSM_REQUIRE(M > 0 && M < (1ll << 31) && K > 0, "csm_embed_bwd: bad shape");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)M), dim3(256), 0, stream, tokens, mask, (const bf16_t*)dh, d_text,
-                       d_audio, K, D, audio_vocab);
-    CSM_CHECK_LAUNCH("csm_embed_bwd");
-    return 0;
-}
-
 extern "C" int csm_embed_bwd_sorted(const long long* sorted_rows, const long long* src_index, long long n_occ, const void* dh,
                                     const void* dseq, long long M, void* g_text, void* g_audio, long long text_rows,
                                     long long n_rows, int D, hipStream_t stream) {
@@ -632,15 +563,6 @@ extern "C" int csm_decoder_input_fwd(const void* hidden, const int* rows, const 
     hipLaunchKernelGGL(decoder_input_kernel, dim3((unsigned)(N * K)), dim3(256), 0, stream, (const bf16_t*)hidden, rows, codes,
                        (const bf16_t*)audio_emb, (bf16_t*)out, K, D, audio_vocab);
     CSM_CHECK_LAUNCH("csm_decoder_input_fwd");
-    return 0;
-}
-
-extern "C" int csm_decoder_input_bwd(const void* dseq, const int* rows, const long long* codes, float* d_hidden,
-                                     float* d_audio, long long N, int K, int D, int audio_vocab, hipStream_t stream) {
-    CSM_REQUIRE(dseq && rows && codes && d_hidden && N > 0 && N * K < (1ll << 31), "csm_decoder_input_bwd: bad arguments");
-    hipLaunchKernelGGL(decoder_input_bwd_kernel, dim3((unsigned)(N * K)), dim3(256), 0, stream, (const bf16_t*)dseq, rows,
-                       codes, d_hidden, d_audio, K, D, audio_vocab);
-    CSM_CHECK_LAUNCH("csm_decoder_input_bwd");
     return 0;
 }
 
@@ -694,20 +616,5 @@ extern "C" int csm_adamw_step(float* master, float* m, float* v, void* param, vo
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 3, 256, g_adamw_blocks)), dim3(256), 0, stream, master, m, v, (bf16_t*)param,
                        (bf16_t*)grad, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, norm_and_coef, grad_mul, zero_grad);
     CSM_CHECK_LAUNCH("csm_adamw_step");
-    return 0;
-}
-
-extern "C" int csm_f32_to_bf16(const float* src, void* dst, long long n, int accumulate, hipStream_t stream) {
-    CSM_REQUIRE(src && dst && n > 0 && (n & 7) == 0, "csm_f32_to_bf16: n must be a positive multiple of 8");
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n >> 3, 256, 4096)), dim3(256), 0, stream, src, (bf16_t*)dst, n,
-                       accumulate);
-    CSM_CHECK_LAUNCH("csm_f32_to_bf16");
-    return 0;
-}
-
-extern "C" int csm_add_f32_into_bf16(void* a, const float* b, long long n, hipStream_t stream) {
-    CSM_REQUIRE(a && b && n > 0 && (n & 7) == 0, "csm_add_f32_into_bf16: n must be a positive multiple of 8");
-    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n >> 3, 256, 4096)), dim3(256), 0, stream, (bf16_t*)a, b, n);
-    CSM_CHECK_LAUNCH("csm_add_f32_into_bf16");
     return 0;
 }

@@ -81,10 +81,8 @@ int csm_swiglu_bwd(const void* gu, const void* dout, void* dgu, long long M, int
 
 /* ---- K1: Model._embed_tokens + mask-mul-sum (model.py:202-217, training/utils.py:85-87) ---------------------- *
  * tokens int64 [M][K+1] (K audio slots then the text slot), mask uint8 [M][K+1]; out bf16 [M][D].
- * Backward scatter-adds into fp32 scratch tables (same shapes as the embeddings). */
+ * The backward is csm_embed_bwd_sorted below. */
 int csm_embed_fwd(const long long* tokens, const uint8_t* mask, const void* text_emb, const void* audio_emb, void* out,
-                  long long M, int K, int D, int audio_vocab, csm_stream_t stream);
-int csm_embed_bwd(const long long* tokens, const uint8_t* mask, const void* dh, float* d_text, float* d_audio,
                   long long M, int K, int D, int audio_vocab, csm_stream_t stream);
 
 /* Deterministic, scratch-free form of the embedding backward: occurrences (embedding row, source row) sorted by
@@ -98,8 +96,6 @@ int csm_rows_add_bf16(void* dst, const int* rows, const void* src, long long N, 
 
 /* depth-decoder teacher forcing (model.py:175-189): out[n][0]=hidden[rows[n]], out[n][i]=audio_emb[code_{i-1}+(i-1)V] */
 int csm_decoder_input_fwd(const void* hidden, const int* rows, const long long* codes, const void* audio_emb, void* out,
-                          long long N, int K, int D, int audio_vocab, csm_stream_t stream);
-int csm_decoder_input_bwd(const void* dseq, const int* rows, const long long* codes, float* d_hidden, float* d_audio,
                           long long N, int K, int D, int audio_vocab, csm_stream_t stream);
 
 /* ---- K9/K11: F.cross_entropy (training/utils.py:102-105) fused with its backward ------------------------------ *
@@ -116,8 +112,6 @@ int csm_adamw_step(float* master, float* m, float* v, void* param, void* grad, l
                    float beta2, float eps, float weight_decay, int step, const float* norm_and_coef /* or NULL */,
                    float grad_mul, int zero_grad /* clear grad in the same pass */, csm_stream_t stream);
 int csm_set_adamw_blocks(int blocks); /* tuning switch */
-int csm_f32_to_bf16(const float* src, void* dst, long long n, int accumulate, csm_stream_t stream);
-int csm_add_f32_into_bf16(void* a, const float* b, long long n, csm_stream_t stream);
 
 /* ---- K14: sample_topk + _multinomial_sample_one_no_sync (model.py:79-96), Exp(1) noise q supplied ---------------- */
 int csm_sample_topk(const float* logits, const float* q, int* out, int rows, int V, int ldl, int topk, float temperature,

@@ -342,11 +342,6 @@ def test_embed(dev):
     dh = rnd((M, cfg.backbone.dim), torch.Generator().manual_seed(9))
     pt = {k: params[k].float().requires_grad_(True) for k in ("text_embeddings.weight", "audio_embeddings.weight")}
     O.embed_masked_sum(pt, cfg, tokens, mask).view(M, -1).backward(dh.float())
-    dt = torch.zeros_like(te, dtype=torch.float32)
-    da = torch.zeros_like(ae, dtype=torch.float32)
-    ops.embed_bwd(tk, mk, dh.to(dev), dt, da, cfg.audio_vocab)
-    close("embed d_text", dt, pt["text_embeddings.weight"].grad, 1e-5)
-    close("embed d_audio", da, pt["audio_embeddings.weight"].grad, 1e-5)
     # sorted / deterministic form, with extra occurrences coming from a second source tensor
     K, V, TV = cfg.n_codebooks, cfg.audio_vocab, cfg.text_vocab
     slot = torch.arange(K + 1)
