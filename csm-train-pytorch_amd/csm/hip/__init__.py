@@ -58,6 +58,13 @@ _SIGS = {
     "csm_attn_decode": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_sample_topk": ([_p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "csm_rvq_encode": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "csm_conv1d_f32": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "csm_conv_transpose1d_f32": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "csm_layernorm_f32": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
+    "csm_linear_f32": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "csm_rope_half_f32": ([_p, _i, _i, _i, _f, _i, _p], _i),
+    "csm_attn_window_f32": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "csm_transpose_f32": ([_p, _p, _i, _i, _p], _i),
     "csm_rvq_decode": ([_p, _p, _p, _i, _i, _i, _i, _p], _i),
 }
 

@@ -137,6 +137,22 @@ int csm_rvq_encode(const float* x, const float* codebooks, long long* codes, int
 int csm_rvq_decode(const long long* codes, const float* codebooks, float* out, int T, int K, int C, int D,
                    csm_stream_t stream);
 
+/* ---- K16 (rest): Mimi codec around the RVQ - SEANet convolutions and the two 8-layer codec transformers, fp32 -------- *
+ * (moshi MimiModel.encode / decode behind generator.py:67-70,117,209).  Activations are [C][T] for the convolutions and
+ * [T][D] for the transformers. */
+int csm_conv1d_f32(const float* x, const float* w, const float* bias, const float* residual, float* y, int C_in, int C_out,
+                   int T_in, int T_out, int k, int stride, int dilation, int pad_left, int pad_mode /*0 zero,1 replicate*/,
+                   int groups, int elu_in, csm_stream_t stream);
+int csm_conv_transpose1d_f32(const float* x, const float* w, const float* bias, float* y, int C_in, int C_out, int T_in, int T_out,
+                             int k, int stride, int crop_left, int groups, int elu_in, csm_stream_t stream);
+int csm_layernorm_f32(const float* x, const float* w, const float* b, float* y, int T, int D, float eps, csm_stream_t stream);
+/* y = act(x W^T); scale != NULL: y = residual + scale[n] * y (layer scale); else y += residual when given; act 1 = GELU */
+int csm_linear_f32(const float* x, const float* W, const float* scale, const float* residual, float* y, int T, int N, int K,
+                   int ldx, int act, csm_stream_t stream);
+int csm_rope_half_f32(float* qkv, int T, int H, int head_dim, float base, int pos0, csm_stream_t stream);
+int csm_attn_window_f32(const float* qkv, float* out, int T, int H, int head_dim, int window, csm_stream_t stream);
+int csm_transpose_f32(const float* in, float* out, int R, int C, csm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
