@@ -110,12 +110,18 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "CSM_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the multi-rank path on a one-GPU box (with gloo)
+        local = int(os.environ["CSM_BENCH_FORCE_DEVICE"])
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("CSM_BENCH_BACKEND", "nccl")        # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from csm.data import SyntheticCSMDataset, collate_variable_length
     from csm.models.model import Model, ModelArgs
