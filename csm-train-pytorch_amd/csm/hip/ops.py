@@ -120,6 +120,31 @@ def colsum_bf16(partials, dst, accumulate=False):
     check(lib.csm_colsum_bf16(partials.data_ptr(), rows, D, dst.data_ptr(), int(accumulate), _stream()), "csm_colsum_bf16")
 
 
+def dropout_bf16(x, out, p, seed, accumulate=False):
+    """out (+)= dropout(x, p) on [M, D] bf16 row-strided matrices; the mask depends only on (seed, row*D + col)."""
+    M, D = x.shape
+    assert out.shape == x.shape and x.stride(1) == 1 and out.stride(1) == 1
+    check(lib.csm_dropout_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, D, float(p), int(seed) & (2 ** 64 - 1),
+                               int(accumulate), _stream()), "csm_dropout_bf16")
+    return out
+
+
+def bias_add_bf16(y, bias):
+    M, D = y.shape
+    assert y.stride(1) == 1 and bias.numel() == D and bias.is_contiguous()
+    check(lib.csm_bias_add_bf16(y.data_ptr(), y.stride(0), bias.data_ptr(), M, D, _stream()), "csm_bias_add_bf16")
+
+
+def bias_grad_bf16(dy, gbias, accumulate=True, slices=64):
+    """gbias (+)= sum over rows of dy [M, D] (bf16, row-strided), fp32 accumulation in two stages."""
+    M, D = dy.shape
+    assert dy.stride(1) == 1
+    slices = max(1, min(slices, (M + 3) // 4))
+    part = torch.empty(slices, D, dtype=torch.float32, device=dy.device)
+    check(lib.csm_colsum_rows_bf16(dy.data_ptr(), dy.stride(0), M, D, part.data_ptr(), slices, _stream()), "csm_colsum_rows_bf16")
+    colsum_bf16(part, gbias, accumulate=accumulate)
+
+
 def rope(qkv, table, S, n_heads_qk, head_dim, pos=None, inverse=False):
     M, ld = qkv.shape
     assert table.dtype == torch.float32 and table.is_contiguous()

@@ -1,7 +1,8 @@
 """LoRA adapters for the HIP path.  Semantics of reference ``src/csm/mlx/components/lora.py``:
 
-  y = x W0^T + (alpha / r) * ((x A^T) B^T),  A ~ N(0, 1/sqrt(in)) of shape [r, in],  B = 0 of shape [out, r]
-  (``LoRALinear`` lora.py:14-105), merge W0 + (alpha/r) B A (lora.py:140-153), applied to both stacks, default
+  y = x W0^T + (alpha / r) * ((drop(x) A^T) B^T) (+ lora_bias),  A ~ N(0, 1/sqrt(in)) [r, in],  B = 0 [out, r],
+  lora_bias = 0 [out] when ``use_bias`` (``LoRALinear`` lora.py:14-105; dropout is inverted dropout on the adapter
+  input only, lora.py:85-90), merge W0 + (alpha/r) B A (lora.py:140-153), applied to both stacks, default
   target modules ["q_proj", "v_proj"], all layers unless ``target_layers`` (``apply_lora_to_model`` lora.py:741-860).
 
 Names are ``{backbone|decoder}.layers.{i}.attn.{q_proj,k_proj,v_proj,output_proj}.lora_{A,B}`` and
@@ -23,15 +24,29 @@ MLP = ("w1", "w2", "w3")
 
 
 class LoRAAdapter:
-    def __init__(self, name, A, B, gA, gB, scaling):
+    def __init__(self, name, A, B, gA, gB, scaling, bias=None, gbias=None, dropout=0.0, seed=0, state=None):
         self.name, self.A, self.B, self.gA, self.gB, self.scaling = name, A, B, gA, gB, scaling
+        self.bias, self.gbias, self.dropout, self.seed, self.state = bias, gbias, float(dropout), int(seed), state
         self.r = A.shape[0]
+        self._draw = None          # dropout seed of the forward whose backward is pending
+
+    def _dropped(self, x):
+        """drop(x): the mask is regenerated from ``self._draw`` (set in forward), never stored."""
+        if self._draw is None:
+            return x
+        return ops.dropout_bf16(x, torch.empty(x.shape, dtype=BF16, device=x.device), self.dropout, self._draw)
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        """y += scaling * (x A^T) B^T ; returns t = x A^T (kept for the backward)."""
+        """y += scaling * (drop(x) A^T) B^T (+ bias); returns t = drop(x) A^T (kept for the backward)."""
+        self._draw = None
+        if self.dropout > 0 and self.state.training:
+            self.state.draws += 1
+            self._draw = (self.seed * 0x9E3779B1 + self.state.draws * 0x85EBCA77) & (2 ** 63 - 1)
         t = torch.empty(x.shape[0], self.r, dtype=BF16, device=x.device)
-        ops.gemm(x, self.A, t)
+        ops.gemm(self._dropped(x), self.A, t)
         ops.gemm(t, self.B, y, y, alpha=self.scaling)
+        if self.bias is not None:
+            ops.bias_add_bf16(y, self.bias)
         return t
 
     @staticmethod
@@ -52,12 +67,19 @@ class LoRAAdapter:
         ops.colsum_bf16(part, out.view(-1), accumulate=True)
 
     def backward(self, x, dy, t, dx):
-        """dB += s dy^T t ; dt = s dy B ; dA += dt^T x ; dx += dt A."""
+        """dB += s dy^T t ; dt = s dy B ; dA += dt^T drop(x) ; dx += mask * (dt A) / (1-p) ; dbias += colsum(dy)."""
         dt = torch.empty_like(t)
         ops.gemm(dy, self.B, dt, None, False, True, alpha=self.scaling)
         self._skinny_wgrad(dy, t, self.gB, self.scaling)
-        self._skinny_wgrad(dt, x, self.gA, 1.0)
-        ops.gemm(dt, self.A, dx, dx, False, True)
+        self._skinny_wgrad(dt, self._dropped(x), self.gA, 1.0)
+        if self._draw is None:
+            ops.gemm(dt, self.A, dx, dx, False, True)
+        else:
+            dxl = torch.empty(x.shape, dtype=BF16, device=x.device)
+            ops.gemm(dt, self.A, dxl, None, False, True)
+            ops.dropout_bf16(dxl, dx, self.dropout, self._draw, accumulate=True)
+        if self.gbias is not None:
+            ops.bias_grad_bf16(dy, self.gbias, accumulate=True)
 
 
 class LoRAState:
@@ -65,14 +87,13 @@ class LoRAState:
 
     def __init__(self, model, r: int, alpha: float, dropout: float, target_modules: List[str],
                  target_layers: Optional[List[int]], use_bias: bool, seed: int = 0):
-        if dropout and dropout > 0:
-            raise NotImplementedError("lora_dropout > 0 is not implemented on the HIP path yet")
-        if use_bias:
-            raise NotImplementedError("lora_use_bias is not implemented on the HIP path yet")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError("lora_dropout must be in [0, 1)")
         if r % 8 != 0:
             raise ValueError("lora_r must be a multiple of 8 (MFMA k-step / 16-byte rows)")
         self.r, self.alpha, self.dropout, self.scaling = r, alpha, dropout, alpha / r
         self.target_modules, self.target_layers, self.use_bias = list(target_modules), target_layers, use_bias
+        self.training, self.draws = True, 0        # dropout is live only while training; draws counts masks drawn
         plan = []
         for prefix, c in (("backbone", model.bb), ("decoder", model.dc)):
             hq, hk = c.num_heads * c.head_dim, c.num_kv_heads * c.head_dim
@@ -88,7 +109,7 @@ class LoRAState:
                     sub = "attn" if mod in ATTN else "mlp"
                     out_f, in_f = dims[mod]
                     plan.append((prefix, i, mod, f"{prefix}.layers.{i}.{sub}.{mod}", out_f, in_f))
-        total = sum(r * in_f + out_f * r for *_, out_f, in_f in plan)
+        total = sum(r * in_f + out_f * r + (out_f if use_bias else 0) for *_, out_f, in_f in plan)
         total = (total + 7) // 8 * 8
         dev = model.device
         self.arena = torch.zeros(total, dtype=BF16, device=dev)
@@ -104,8 +125,13 @@ class LoRAState:
             B = self.arena[off:off + out_f * r].view(out_f, r)
             gB = self.grad_arena[off:off + out_f * r].view(out_f, r)
             off += out_f * r
+            bias = gbias = None
+            if use_bias:
+                bias, gbias = self.arena[off:off + out_f], self.grad_arena[off:off + out_f]
+                off += out_f
             A.copy_((torch.randn(r, in_f, generator=g, device=dev) / math.sqrt(in_f)).to(BF16))
-            self.adapters[(prefix, i, mod)] = LoRAAdapter(name, A, B, gA, gB, self.scaling)
+            self.adapters[(prefix, i, mod)] = LoRAAdapter(name, A, B, gA, gB, self.scaling, bias, gbias, dropout,
+                                                          seed * 1000003 + len(self.adapters), self)
 
     def get(self, prefix, layer, module):
         return self.adapters.get((prefix, layer, module))
@@ -114,9 +140,11 @@ class LoRAState:
         for ad in self.adapters.values():
             yield f"{ad.name}.lora_A", ad.A
             yield f"{ad.name}.lora_B", ad.B
+            if ad.bias is not None:
+                yield f"{ad.name}.lora_bias", ad.bias
 
     def num_params(self) -> int:
-        return sum(ad.A.numel() + ad.B.numel() for ad in self.adapters.values())
+        return sum(t.numel() for _, t in self.named_tensors())
 
 
 def apply_lora_to_model(model, r: int = 8, alpha: float = 16.0, dropout: float = 0.0,

@@ -145,12 +145,16 @@ class CSMLoRATrainer:
         """Reference mlx_trainer.py:878-972 (at most 10 batches, line 899)."""
         n = min(10, len(val_dataset) // batch_size)
         total = 0.0
-        with torch.no_grad():
-            for i in range(n):
-                b = val_dataset.get_batch(i, batch_size)
-                loss, _ = compute_loss(self.model, _to_torch(b["input_tokens"]), _to_torch(b["input_masks"]),
-                                       _to_torch(b["target_audio_tokens"]), self.semantic_weight, self.acoustic_weight)
-                total += float(loss)
+        self.model.lora.training = False          # adapter dropout off while scoring
+        try:
+            with torch.no_grad():
+                for i in range(n):
+                    b = val_dataset.get_batch(i, batch_size)
+                    loss, _ = compute_loss(self.model, _to_torch(b["input_tokens"]), _to_torch(b["input_masks"]),
+                                           _to_torch(b["target_audio_tokens"]), self.semantic_weight, self.acoustic_weight)
+                    total += float(loss)
+        finally:
+            self.model.lora.training = True
         return total / max(1, n)
 
     def save_model(self, save_path: str, save_mode: str = "lora"):

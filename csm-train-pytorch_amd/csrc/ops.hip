@@ -149,6 +149,72 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LoRA side ops
+// Inverted dropout on a [M, D] bf16 matrix with row stride ld (reference lora.py:88-90, mlx nn.dropout: kept values are
+// scaled by 1/(1-p)).  The keep decision for element (row, col) is a pure function of (seed, row*D + col) - a
+// splitmix64 finaliser, 16 bits per element against the threshold p*65536 - so the backward regenerates the very same
+// mask from the seed instead of storing it.  accumulate = 1: out += dropout(in).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
+                                                      long long M, int D, uint32_t thresh, float scale, uint64_t seed, int accumulate) {
+    const int cpr = D >> 3;                                  // 16-byte chunks per row
+    const long long total = M * cpr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cpr;
+        const int ch = (int)(i - r * cpr);
+        const uint64_t e = (uint64_t)(r * D + ch * 8) >> 2;   // one 64-bit draw covers 4 elements
+        const uint64_t h0 = mix64(seed ^ (e * 0xd1342543de82ef95ull)), h1 = mix64(seed ^ ((e + 1) * 0xd1342543de82ef95ull));
+        float f[8], g[8];
+        unpack8(*reinterpret_cast<const U4*>(in + r * ld_in + ch * 8), f);
+        if (accumulate) unpack8(*reinterpret_cast<const U4*>(out + r * ld_out + ch * 8), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t u = (uint32_t)(((j < 4 ? h0 : h1) >> (16 * (j & 3))) & 0xffffu);
+            const float v = u >= thresh ? f[j] * scale : 0.f;
+            f[j] = accumulate ? g[j] + v : v;
+        }
+        *reinterpret_cast<U4*>(out + r * ld_out + ch * 8) = pack8(f);
+    }
+}
+
+// y[r, :] += bias for a [M, D] bf16 matrix with row stride ld (LoRA bias, reference lora.py:100-102)
+__global__ __launch_bounds__(256) void bias_add_kernel(bf16_t* __restrict__ y, int ld, const bf16_t* __restrict__ bias, long long M, int D) {
+    const int cpr = D >> 3;
+    const long long total = M * cpr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cpr;
+        const int ch = (int)(i - r * cpr);
+        float f[8], b[8];
+        unpack8(*reinterpret_cast<const U4*>(y + r * ld + ch * 8), f);
+        unpack8(*reinterpret_cast<const U4*>(bias + ch * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += b[j];
+        *reinterpret_cast<U4*>(y + r * ld + ch * 8) = pack8(f);
+    }
+}
+
+// partial column sums of a bf16 [M, D] matrix (row stride ld): block (cb, sl) sums rows sl, sl+S, ... of 64 columns
+// into partials[sl][col] (fp32); colsum_kernel finishes.  Used for d(bias) = sum_rows dy.
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const bf16_t* __restrict__ x, int ld, long long M, int D,
+                                                          float* __restrict__ partials) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int sl = blockIdx.y, S = gridDim.y;
+    float t = 0.f;
+    if (col < D)
+        for (long long r = (long long)sl * 4 + q; r < M; r += (long long)S * 4) t += bf2f(x[r * ld + col]);
+    red[q][c] = t;
+    __syncthreads();
+    if (q == 0 && col < D) partials[(size_t)sl * D + col] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
 // ------------------------------------------------------------------------------------------------ RoPE
 // torchtune Llama3ScaledRoPE on the fused qkv buffer, in place: interleaved pairs (2i, 2i+1) of every q and k
 // head rotated by pos*theta'_i (table [P][hd/2][2] = cos,sin fp32, built on the host exactly as the oracle does).
@@ -492,6 +558,36 @@ extern "C" int csm_colsum_bf16(const float* partials, int rows, int D, void* dst
     CSM_REQUIRE(partials && dst && rows > 0 && D > 0, "csm_colsum_bf16: bad arguments");
     hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, rows, D, (bf16_t*)dst, accumulate);
     CSM_CHECK_LAUNCH("csm_colsum_bf16");
+    return 0;
+}
+
+extern "C" int csm_dropout_bf16(const void* in, int ld_in, void* out, int ld_out, long long M, int D, float p,
+                                unsigned long long seed, int accumulate, hipStream_t stream) {
+    CSM_REQUIRE(in && out && M > 0 && D > 0 && D % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ld_in >= D && ld_out >= D,
+                "csm_dropout_bf16: bad arguments (D and strides must be multiples of 8)");
+    CSM_REQUIRE(p >= 0.f && p < 1.f, "csm_dropout_bf16: p must be in [0, 1)");
+    const uint32_t thresh = (uint32_t)(p * 65536.0f + 0.5f);
+    const long long total = M * (D / 8);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, M, D,
+                       thresh, 1.0f / (1.0f - thresh / 65536.0f), (uint64_t)seed, accumulate);
+    CSM_CHECK_LAUNCH("csm_dropout_bf16");
+    return 0;
+}
+
+extern "C" int csm_bias_add_bf16(void* y, int ld, const void* bias, long long M, int D, hipStream_t stream) {
+    CSM_REQUIRE(y && bias && M > 0 && D > 0 && D % 8 == 0 && ld % 8 == 0 && ld >= D, "csm_bias_add_bf16: bad arguments");
+    const long long total = M * (D / 8);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(bias_add_kernel, dim3(blocks), dim3(256), 0, stream, (bf16_t*)y, ld, (const bf16_t*)bias, M, D);
+    CSM_CHECK_LAUNCH("csm_bias_add_bf16");
+    return 0;
+}
+
+extern "C" int csm_colsum_rows_bf16(const void* x, int ld, long long M, int D, float* partials, int slices, hipStream_t stream) {
+    CSM_REQUIRE(x && partials && M > 0 && D > 0 && ld >= D && slices > 0 && slices <= 65535, "csm_colsum_rows_bf16: bad arguments");
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3((D + 63) / 64, slices), dim3(256), 0, stream, (const bf16_t*)x, ld, M, D, partials);
+    CSM_CHECK_LAUNCH("csm_colsum_rows_bf16");
     return 0;
 }
 

@@ -62,6 +62,15 @@ int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rstd, const v
                     float* dscale_partials /* [csm_rmsnorm_bwd_blocks()][D] or NULL */, int M, int D, csm_stream_t stream);
 int csm_colsum_bf16(const float* partials, int rows, int D, void* dst, int accumulate, csm_stream_t stream);
 
+/* ---- LoRA side ops (reference mlx/components/lora.py:85-102): inverted dropout of the adapter input (mask is a pure
+ * function of (seed, row*D+col), so the backward regenerates it; accumulate=1: out += dropout(in)), the optional
+ * lora_bias add, and the bf16 column sums that give d(lora_bias) (finish with csm_colsum_bf16 on the partials). */
+int csm_dropout_bf16(const void* in, int ld_in, void* out, int ld_out, long long M, int D, float p, unsigned long long seed,
+                     int accumulate, csm_stream_t stream);
+int csm_bias_add_bf16(void* y, int ld, const void* bias, long long M, int D, csm_stream_t stream);
+int csm_colsum_rows_bf16(const void* x, int ld, long long M, int D, float* partials /* [slices][D] */, int slices,
+                         csm_stream_t stream);
+
 /* ---- K4: torchtune Llama3ScaledRoPE (rope_base=500000, scale_factor=32: model.py:23-24,40-41), interleaved
  * pairs, in place on the q and k heads of the fused qkv buffer; inverse=1 is the backward rotation.
  * table = [P][head_dim/2][2] (cos,sin) fp32; pos = int32 [M] or NULL (position = row % S). */

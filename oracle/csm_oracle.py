@@ -190,11 +190,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = 
 
 
 def lora_delta(x: torch.Tensor, lora: Optional[Dict[str, torch.Tensor]], name: str, scaling: float) -> torch.Tensor:
-    """(alpha/r) * (x A^T) B^T, or 0 when the module has no adapter."""
+    """(alpha/r) * (drop(x) A^T) B^T (+ lora_bias), or 0 when the module has no adapter (lora.py:71-105).
+    Dropout is expressed through an optional ``{name}.lora_dropout_scale`` entry: the inverted-dropout multiplier
+    (0 or 1/(1-p)) per element of x, supplied by the test so that both sides use the same mask."""
     if lora is None or f"{name}.lora_A" not in lora:
         return 0.0
     A, Bm = lora[f"{name}.lora_A"], lora[f"{name}.lora_B"]
-    return scaling * ((x @ A.t()) @ Bm.t())
+    ds = lora.get(f"{name}.lora_dropout_scale")
+    xl = x if ds is None else x * ds.reshape(x.shape).to(x.dtype)
+    out = scaling * ((xl @ A.t()) @ Bm.t())
+    if f"{name}.lora_bias" in lora:
+        out = out + lora[f"{name}.lora_bias"]
+    return out
 
 
 def transformer(params: Dict[str, torch.Tensor], prefix: str, c: StackCfg, h: torch.Tensor,

@@ -187,6 +187,55 @@ def test_lora_step(dev):
     assert rel(after, before) < 2e-3
 
 
+def test_lora_dropout_and_bias_step(dev):
+    """lora_dropout > 0 and lora_use_bias (reference lora.py:85-102): the oracle is given the very masks the HIP path
+    drew (regenerated from each adapter's seed), so loss and every adapter gradient can be compared exactly as above."""
+    from csm.hip import ops
+    from csm.training.lora import apply_lora_to_model
+    from csm.training.utils import compute_loss
+    m, p32, pq = tiny_model(dev)
+    m.acoustic_mode = "all"
+    p = 0.25
+    apply_lora_to_model(m, r=8, alpha=16.0, dropout=p, target_modules=["q_proj", "output_proj", "w1"], use_bias=True, seed=3)
+    with torch.no_grad():
+        g = torch.Generator(device=dev).manual_seed(4)
+        for ad in m.lora.adapters.values():
+            ad.B.copy_((torch.randn(ad.B.shape, generator=g, device=dev) * 0.05).to(BF))
+            ad.bias.copy_((torch.randn(ad.bias.shape, generator=g, device=dev) * 0.02).to(BF))
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=8)
+    total, _ = compute_loss(m, tokens, mask, targets)
+    total.backward()
+    lora = {k: v.detach().float().cpu().requires_grad_(True) for k, v in m.get_lora_params().items()}
+    assert any(k.endswith("lora_bias") for k in lora)
+    Bt, St = tokens.shape[:2]
+    n_rows = {"backbone": Bt * St, "decoder": Bt * (St - 1) * m.args.audio_num_codebooks}   # decoder: every frame trains
+    for ad in m.lora.adapters.values():
+        assert ad._draw is not None
+        in_f = ad.A.shape[1]
+        rows = n_rows[ad.name.split(".")[0]]
+        ones = torch.ones(rows, in_f, dtype=BF, device=dev)
+        keep = ops.dropout_bf16(ones, torch.empty_like(ones), p, ad._draw) != 0
+        frac = keep.float().mean().item()
+        assert abs(frac - (1 - p)) < 0.02, (ad.name, frac)
+        lora[f"{ad.name}.lora_dropout_scale"] = keep.float().cpu() / (1 - p)
+    rt, _ = O.compute_loss(pq, TINY, tokens, mask, targets, acoustic_rows=None, lora=lora, lora_scaling=2.0)
+    rt.backward()
+    assert rel(total, rt) < 1e-3, (float(total), float(rt))
+    for ad in m.lora.adapters.values():
+        gclose(f"{ad.name}.lora_A grad", ad.gA, lora[f"{ad.name}.lora_A"].grad, 5e-2)
+        gclose(f"{ad.name}.lora_B grad", ad.gB, lora[f"{ad.name}.lora_B"].grad, 5e-2)
+        gclose(f"{ad.name}.lora_bias grad", ad.gbias, lora[f"{ad.name}.lora_bias"].grad, 5e-2)
+    # a second forward draws fresh masks; with training off the adapters are deterministic
+    d0 = m.lora.draws
+    compute_loss(m, tokens, mask, targets)
+    assert m.lora.draws > d0
+    m.lora.training = False
+    with torch.no_grad():
+        a1, _ = compute_loss(m, tokens, mask, targets)
+        a2, _ = compute_loss(m, tokens, mask, targets)
+    assert float(a1) == float(a2)
+
+
 def test_generate_frame_matches_reference_fixture(dev):
     """Frames sampled by the REFERENCE's generate_frame (fp32, stand-in stacks) for fixed noise: indices bit-exact."""
     m, p32, pq = tiny_model(dev)
