@@ -51,7 +51,25 @@ class GemmTimer:
     def __enter__(self):
         from csm.hip import ops
         self.ops, self.orig = ops, ops.gemm
+        self.orig_fwd, self.orig_bwd = ops.linear_swiglu_fwd, ops.linear_dx_swiglu_bwd
         timer = self
+
+        def ev():
+            return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def fused_fwd(x, w13, gu, act):           # gu[M,2F] = x w13^T, act = SwiGLU(gu) in the epilogue
+            e0, e1 = ev()
+            e0.record(); timer.orig_fwd(x, w13, gu, act); e1.record()
+            M, K = x.shape
+            N = w13.shape[0]
+            timer.records.append(("nt_fwd_bf16", 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N + M * N // 2)))
+
+        def fused_bwd(dy, w2, gu, dgu):           # dgu[M,2F] = SwiGLU'(gu) . (dy w2) in the epilogue
+            e0, e1 = ev()
+            e0.record(); timer.orig_bwd(dy, w2, gu, dgu); e1.record()
+            M, K = dy.shape
+            F = w2.shape[1]
+            timer.records.append(("nn_dgrad_bf16", 2.0 * M * F * K, e0, e1, 2.0 * (M * K + F * K + 4 * M * F)))
 
         def timed(A, B, C, R=None, transA=False, transB=False, alpha=1.0, batch=1, sA=0, sB=0, sC=0, sR=0):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,25 +80,40 @@ class GemmTimer:
             K = A.shape[0] if transA else A.shape[1]
             kind = {(False, False): "nt_fwd", (False, True): "nn_dgrad", (True, True): "tn_wgrad", (True, False): "tt"}[(transA, transB)]
             kind += "_f32" if C.dtype == torch.float32 else "_bf16"
-            timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1))
+            esz = C.element_size()
+            timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1, batch * (2.0 * (M * K + N * K) + esz * M * N)))
             return out
 
-        ops.gemm = timed
+        ops.gemm, ops.linear_swiglu_fwd, ops.linear_dx_swiglu_bwd = timed, fused_fwd, fused_bwd
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm = self.orig
+        self.ops.gemm, self.ops.linear_swiglu_fwd, self.ops.linear_dx_swiglu_bwd = self.orig, self.orig_fwd, self.orig_bwd
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for kind, flop, e0, e1 in self.records:
-            d = agg.setdefault(kind, [0.0, 0.0, 0])
+        for kind, flop, e0, e1, nbytes in self.records:
+            d = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             d[0] += flop
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
+            d[3] += nbytes
         return {k: {"tflops": v[0] / v[1] / 1e12, "time_ms": v[1] * 1e3, "launches": v[2], "avg_us": v[1] / v[2] * 1e6,
-                    "flop": v[0]} for k, v in agg.items() if v[1] > 0}
+                    "flop": v[0], "operand_bytes_per_launch": v[3] / v[2]} for k, v in agg.items() if v[1] > 0}
+
+
+def pmc_traffic(kind):
+    """HBM-side bytes per launch of a GEMM kind from the committed rocprofv3 PMC passes over this same command
+    (profiles/run_pmc_bench_r01.sh -> profiles/r01_bench_pmc_traffic.json); None when the file is not there.  Counters
+    cannot be read from inside the timed process, so this is the profile's figure, not a live one."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path)).get(kind)
+    if not t:
+        return None, None
+    return t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"], "profiles/r01_bench_pmc_traffic.json"
 
 
 def cpu_baseline(model, cfg_fn, seq, seed, sw, aw):
@@ -187,9 +220,11 @@ def main():
         dom = max(bf.items(), key=lambda kv: kv[1]["time_ms"]) if bf else (None, None)
         roof = None
         if dom[0] is not None:
+            traffic, traffic_src = pmc_traffic(dom[0]) if (a.batch, a.seq, a.mode, a.lora, a.tiny) == (4, 2048, "C", False, False) else (None, None)
             roof = {"bound": "mfma", "kernel": f"gemm_kernel<{dom[0]}>", "achieved": round(dom[1]["tflops"], 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": None, "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
+                    "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                    "operand_bytes_per_launch": round(dom[1]["operand_bytes_per_launch"]), "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
                     "all_gemm_variants": {k: {"tflops": round(v["tflops"], 1), "ms_per_step": round(v["time_ms"], 2),
                                               "launches": v["launches"]} for k, v in kinds.items()}}
         out = {

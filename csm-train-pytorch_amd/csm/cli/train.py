@@ -57,6 +57,7 @@ def main(argv=None):
         trainer.model = Model(csm_1b_args(), device=device, seed=0)
     trainer.model.acoustic_mode = args.acoustic_mode
     trainer.num_workers = args.num_workers
+    trainer.ignore_padding = args.ignore_padding
     train_ds, val_ds = load_datasets(args)
     trainer.prepare_optimizer(freeze_backbone=args.freeze_backbone, freeze_decoder=args.freeze_decoder,
                               freeze_embeddings=args.freeze_embeddings)

@@ -1,36 +1,8 @@
-"""Batch layout helpers (the part of reference ``src/csm/data/training_data.py`` the hot loop consumes).
-
-Audio I/O, segmentation and the contextual-example generator are out of scope for this tier; what the
-trainers need is the collate rule of ``collate_variable_length`` (training_data.py:379-408) and a loader factory
-with the signature of ``create_dataloader`` (training_data.py:361-376).
-"""
-from typing import Dict, List
-
+"""Seeded synthetic interleaved batches - what bench.py and the plumbing tests train on."""
 import torch
-from torch.utils.data import DataLoader, Dataset
+from torch.utils.data import Dataset
 
-
-def collate_variable_length(batch: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
-    """Zero-pad ``input_tokens`` [S,33] / ``input_masks`` [S,33] / ``target_audio_tokens`` [T,32] to the batch max."""
-    max_s = max(b["input_tokens"].shape[0] for b in batch)
-    max_t = max(b["target_audio_tokens"].shape[0] for b in batch)
-    n = len(batch)
-    k1 = batch[0]["input_tokens"].shape[1]
-    k = batch[0]["target_audio_tokens"].shape[1]
-    tokens = torch.zeros(n, max_s, k1, dtype=torch.long)
-    masks = torch.zeros(n, max_s, k1, dtype=torch.bool)
-    targets = torch.zeros(n, max_t, k, dtype=torch.long)
-    for i, b in enumerate(batch):
-        s, t = b["input_tokens"].shape[0], b["target_audio_tokens"].shape[0]
-        tokens[i, :s] = b["input_tokens"]
-        masks[i, :s] = b["input_masks"]
-        targets[i, :t] = b["target_audio_tokens"]
-    return {"input_tokens": tokens, "input_masks": masks, "target_audio_tokens": targets}
-
-
-def create_dataloader(dataset: Dataset, batch_size: int, shuffle: bool = True, num_workers: int = 4) -> DataLoader:
-    return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
-                      collate_fn=collate_variable_length, pin_memory=True)
+from .training_data import collate_variable_length
 
 
 class SyntheticCSMDataset(Dataset):

@@ -205,8 +205,11 @@ class Engine:
         tk = tokens.reshape(M, K1).to(device=dev, dtype=torch.int64).contiguous()
         mk = masks.reshape(M, K1).to(device=dev, dtype=torch.uint8).contiguous()
         tg = targets.to(device=dev, dtype=torch.int64)
-        if int(tg.max()) >= V or int(tg.min()) < 0:
+        ign = getattr(m, "target_ignore_index", None)     # None: reference behaviour, every row counts (utils.py:102-105)
+        if int(tg.max()) >= V or (ign is None and int(tg.min()) < 0):
             raise ValueError("target_audio_tokens out of range for audio_vocab_size")
+        if ign is not None and bool(((tg < 0) & (tg != ign)).any()):
+            raise ValueError(f"negative target_audio_tokens other than the ignore index {ign}")
 
         h0 = torch.empty(M, d, dtype=BF16, device=dev)
         ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, V)
@@ -218,7 +221,8 @@ class Engine:
         t0 = torch.full((B, S), -1, dtype=torch.int64, device=dev)
         t0[:, :S - 1] = tg[:, :S - 1, 0]
         t0 = t0.reshape(M).contiguous()
-        n_sem = B * (S - 1)
+        # with an ignore index the mean runs over the labelled rows only (torch CE semantics); the kernel skips t < 0
+        n_sem = B * (S - 1) if ign is None else max(1, int((t0 >= 0).sum()))
         rows_loss = torch.empty(M, dtype=F32, device=dev)
         ops.ce_fwd_bwd(logits, t0, rows_loss, None, V, 0.0)
         sem = torch.empty(1, dtype=F32, device=dev)
@@ -227,7 +231,7 @@ class Engine:
         ac = torch.zeros(1, dtype=F32, device=dev)
         dec = None
         if m.acoustic_mode != "off":
-            rows = self._acoustic_rows(B, S, acoustic_rows)
+            rows = self._acoustic_rows(B, S, acoustic_rows, t0 if ign is not None else None)
             dec = self._decoder_forward(hidden, rows, tg, B, S, save)
             ops.reduce_sum(dec["rows_loss"], ac, 1.0 / dec["n_rows"])
         total = semantic_weight * sem + acoustic_weight * ac
@@ -236,14 +240,22 @@ class Engine:
                               sw=float(semantic_weight), aw=float(acoustic_weight))
         return total[0], sem[0], ac[0]
 
-    def _acoustic_rows(self, B, S, rows):
-        """Flattened (b*S + p) indices, p < S-1, of the positions whose frame trains the depth decoder."""
+    def _acoustic_rows(self, B, S, rows, t0=None):
+        """Flattened (b*S + p) indices, p < S-1, of the positions whose frame trains the depth decoder.  ``t0`` (the
+        flattened codebook-0 labels, negative = ignored) restricts the choice to labelled frames."""
         dev = self.m.device
         if rows is not None:
             r = rows.to(device=dev, dtype=torch.int64)            # given over the B*(S-1) row space of compute_loss
             b, p = r // (S - 1), r % (S - 1)
-            return (b * S + p).to(torch.int32).contiguous()
+            r = b * S + p
+            if t0 is not None:
+                r = r[t0[r] >= 0]
+            return r.to(torch.int32).contiguous()
         allr = (torch.arange(B, device=dev)[:, None] * S + torch.arange(S - 1, device=dev)[None, :]).reshape(-1)
+        if t0 is not None:
+            allr = allr[t0[allr] >= 0]
+            if allr.numel() == 0:
+                raise ValueError("no labelled audio frame in the batch")
         if self.m.acoustic_mode == "all":
             return allr.to(torch.int32).contiguous()
         n = max(1, int(round(allr.numel() * self.m.acoustic_fraction)))

@@ -26,12 +26,14 @@ class Segment:
     audio: torch.Tensor  # (num_samples,), sample_rate = 24_000
 
 
-def load_llama3_tokenizer():
-    """Reference generator.py:28-45 (needs the Hugging Face hub or a local cache of meta-llama/Llama-3.2-1B)."""
+def load_llama3_tokenizer(path: str = "meta-llama/Llama-3.2-1B"):
+    """Reference generator.py:28-45 (needs the Hugging Face hub, a local cache of meta-llama/Llama-3.2-1B, or ``path`` =
+    a local directory holding that tokenizer's files)."""
+    import os
     from tokenizers.processors import TemplateProcessing
     from transformers import AutoTokenizer
 
-    tokenizer = AutoTokenizer.from_pretrained("meta-llama/Llama-3.2-1B")
+    tokenizer = AutoTokenizer.from_pretrained(path, local_files_only=os.path.isdir(path))
     bos, eos = tokenizer.bos_token, tokenizer.eos_token
     tokenizer._tokenizer.post_processor = TemplateProcessing(
         single=f"{bos}:0 $A:0 {eos}:0", pair=f"{bos}:0 $A:0 {eos}:0 {bos}:1 $B:1 {eos}:1",
@@ -83,8 +85,11 @@ class Generator:
 
     @torch.inference_mode()
     def generate(self, text: str, speaker: int, context: List[Segment], max_audio_length_ms: float = 90_000,
-                 temperature: float = 0.9, topk: int = 50) -> torch.Tensor:
-        """Reference generator.py:147-218."""
+                 temperature: float = 0.9, topk: int = 50, eos_check_every: int = 8) -> torch.Tensor:
+        """Reference generator.py:147-218.  The reference tests every frame for EOS on the host (one device sync per
+        frame, generator.py:196-199); here the all-zero test runs on the device and the host looks at it once per
+        ``eos_check_every`` frames, so the frame graphs are enqueued back to back.  The audio returned is the same: frames
+        sampled past the EOS frame are dropped."""
         self._model.reset_caches()
         max_audio_frames = int(max_audio_length_ms / 80)
         tokens, masks = [], []
@@ -104,13 +109,22 @@ class Generator:
         if curr_tokens.size(1) >= max_seq_len:
             raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {max_seq_len}")
         K = self._model.args.audio_num_codebooks
-        for _ in range(max_audio_frames):
+        audio_mask = torch.cat([torch.ones(1, K, dtype=torch.bool), torch.zeros(1, 1, dtype=torch.bool)], dim=1).unsqueeze(1).to(self.device)
+        pad = torch.zeros(1, 1, dtype=torch.long, device=self.device)
+        checked = 0                                   # frames [0, checked) are known not to be EOS
+        step = max(1, int(eos_check_every))
+        for i in range(max_audio_frames):
             sample = self._model.generate_frame(curr_tokens, curr_mask, curr_pos, temperature, topk)
-            if torch.all(sample == 0):
-                break  # eos
             samples.append(sample)
-            curr_tokens = torch.cat([sample.long(), torch.zeros(1, 1).long().to(self.device)], dim=1).unsqueeze(1)
-            curr_mask = torch.cat([torch.ones(1, K).bool().to(self.device), torch.zeros(1, 1).bool().to(self.device)], dim=1).unsqueeze(1)
+            if len(samples) - checked >= step or i == max_audio_frames - 1:
+                eos = (torch.cat(samples[checked:], 0) == 0).all(dim=1)                 # one host look per chunk
+                hit = eos.nonzero()
+                if hit.numel():
+                    samples = samples[:checked + int(hit[0])]
+                    break
+                checked = len(samples)
+            curr_tokens = torch.cat([sample.long(), pad], dim=1).unsqueeze(1)
+            curr_mask = audio_mask
             curr_pos = curr_pos[:, -1:] + 1
         if not samples:
             return torch.zeros(0, device=self.device)
@@ -128,8 +142,15 @@ class Generator:
             w.writeframes(pcm)
 
 
-def load_csm_1b(ckpt_path: str = "ckpt.pt", device: str = "cuda", text_tokenizer=None, audio_tokenizer=None) -> Generator:
-    """Reference generator.py:221-244."""
+def load_csm_1b(ckpt_path: str = "ckpt.pt", device: str = "cuda", text_tokenizer=None, audio_tokenizer=None,
+                mimi_weights: str = None, tokenizer_path: str = None) -> Generator:
+    """Reference generator.py:221-244.  ``mimi_weights`` / ``tokenizer_path`` name local files for the two tokenizers the
+    reference pulls from the hub."""
+    if audio_tokenizer is None and mimi_weights:
+        from .codec import load_mimi
+        audio_tokenizer = load_mimi(mimi_weights, device=device)
+    if text_tokenizer is None and tokenizer_path:
+        text_tokenizer = load_llama3_tokenizer(tokenizer_path)
     args = ModelArgs(backbone_flavor="llama-1B", decoder_flavor="llama-100M", text_vocab_size=128256,
                      audio_vocab_size=2051, audio_num_codebooks=32)
     model = Model(args, device=device)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
+LIB_PATH = os.environ.get("CSM_HIP_LIB") or os.path.join(_HERE, "libcsm_hip.so")   # override: kernel experiments only
 
 
 class CsmHipError(RuntimeError):

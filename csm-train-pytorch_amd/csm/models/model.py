@@ -160,6 +160,7 @@ class Model(nn.Module):
         self.lora = None                                      # set by csm.training.lora.apply_lora_to_model
         self.acoustic_mode = "off"                            # "off" (reference placeholder) | "all" | "amortized"
         self.acoustic_fraction = 1.0 / 16.0
+        self.target_ignore_index = None                       # e.g. -100: padded target frames leave the loss (data.IGNORE_INDEX)
         self._tables: Dict[str, torch.Tensor] = {}
         self._engine = None
         self._init_seed = seed

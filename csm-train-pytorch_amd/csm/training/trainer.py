@@ -103,17 +103,24 @@ class CSMTrainer:
               val_every: int = 100, save_every: int = 500, max_grad_norm: float = 1.0, resume_from: Optional[str] = None):
         """Reference trainer.py:175-357."""
         nw = getattr(self, "num_workers", 2)
+        # ignore_padding (not in the reference): pad targets with -100 so padded frames leave the loss (SURVEY 8f #4)
+        pad = 0
+        if getattr(self, "ignore_padding", False):
+            from ..data.training_data import IGNORE_INDEX
+            pad = self.model.target_ignore_index = IGNORE_INDEX
         if GradSync.active():
             # data parallel: every rank walks its own shard of the dataset (new capability, see training/dp.py)
+            from functools import partial
             from torch.utils.data import DataLoader
             from torch.utils.data.distributed import DistributedSampler
             from ..data import collate_variable_length
             sampler = DistributedSampler(train_dataset, shuffle=True, drop_last=True)
             train_loader = DataLoader(train_dataset, batch_size=batch_size, sampler=sampler, num_workers=nw,
-                                      collate_fn=collate_variable_length, pin_memory=True, drop_last=True)
+                                      collate_fn=partial(collate_variable_length, target_pad=pad), pin_memory=True, drop_last=True)
         else:
-            train_loader = create_dataloader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=nw)
-        val_loader = create_dataloader(val_dataset, batch_size=batch_size, shuffle=False, num_workers=nw) if val_dataset else None
+            train_loader = create_dataloader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=nw, target_pad=pad)
+        val_loader = (create_dataloader(val_dataset, batch_size=batch_size, shuffle=False, num_workers=nw, target_pad=pad)
+                      if val_dataset else None)
         if self.optimizer is None:
             self.prepare_optimizer()
         if resume_from:

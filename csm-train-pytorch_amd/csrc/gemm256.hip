@@ -174,6 +174,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args g) {
 // ph3 (ph3 drains its prefetch reads before the barrier), giving the DMA order
 //     ph1(t): A1(t+1) -> buf^1    ph2(t): B0(t+2) -> buf    ph3(t): B1(t+2) -> buf    ph4(t): A0(t+2) -> buf
 // and one counted wait per K-tile at the end of ph3 (vmcnt(4): everything up to A1(t+1) has landed).
+// Experiment switches for tools/probes/ablate_gemm.sh (never set in the shipped build): drop one ingredient of the main
+// loop to see what bounds it.  bit0: no LDS-DMA after the prologue; bit1: no fragment reads; bit2: no MFMA; bit3: no barrier.
+#ifndef CSM_ABLATE
+#define CSM_ABLATE 0
+#endif
+constexpr bool ABL_G = CSM_ABLATE & 1, ABL_L = CSM_ABLATE & 2, ABL_M = CSM_ABLATE & 4, ABL_B = CSM_ABLATE & 8;
+constexpr bool EARLY_B = CSM_ABLATE & 32;    // with EARLY_A1: B halves of tile t+2 in ph1/ph2 instead of ph2/ph3
+constexpr bool EARLY_A1 = CSM_ABLATE & 16;   // issue both A halves of tile t+2 in ph4(t) (one more phase of latency slack for A1)
+
 template <int TA, int TB, typename OutT>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -210,26 +219,30 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     // LDS map (160 KiB): A double-buffered [2][2 halves] at 0..64 KiB, B TRIPLE-buffered [3][2 halves] at 64..160 KiB
     auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
     auto slotB = [&](int b3, int h) { return smem + 4 * HALF + b3 * (2 * HALF) + h * HALF; };
-    auto issueA = [&](int h, int tile, int b) { issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slotA(b, h)); };
-    auto issueB = [&](int h, int tile, int b3) { issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slotB(b3, h)); };
+    auto issueA = [&](int h, int tile, int b) { if (ABL_G && tile >= 2) return; issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slotA(b, h)); };
+    auto issueB = [&](int h, int tile, int b3) { if (ABL_G && tile >= 2) return; issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slotB(b3, h)); };
     constexpr int NRA = (TA == 0) ? 4 : 8;     // LDS read instructions per prefetched A pair
 
     issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
-    if (nt > 1) { issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1); WAIT_VM(6); } else { WAIT_VM(0); }
+    if (nt > 1) {
+        issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1);
+        if (EARLY_A1) { issueA(1, 1, 1); WAIT_VM(8); } else { WAIT_VM(6); }
+    } else { WAIT_VM(0); }
     BARRIER();
 
     Frags<TB, 4> fb;
     Frags<TA, 2> fa0, fa1;
     fa0.load(slotA(0, a_half), 0, lane);
+    if (ABL_L) { fb.load(slotB(0, b_half), b_off, lane); fa1.load(slotA(0, a_half), 32, lane); }
     int b3 = 0;   // t % 3
 #define WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MFMA_PAIR(FA, MI)                                                                                              \
-    __builtin_amdgcn_s_setprio(1);                                                                                     \
+    if (!ABL_M) { __builtin_amdgcn_s_setprio(1);                                                                                     \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
                 acc[MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), FA.get(i, ks), acc[MI + i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0); }
 
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
@@ -237,28 +250,29 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
         const char* la = slotA(b, a_half);
         const char* lb = slotB(b3, b_half);
         // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
-        if (t + 1 < nt) issueA(1, t + 1, b ^ 1);
-        fb.load(lb, b_off, lane);
-        fa1.load(la, 32, lane);
+        if (!EARLY_A1 && t + 1 < nt) issueA(1, t + 1, b ^ 1);
+        if (EARLY_B && t + 2 < nt) issueB(0, t + 2, b3n);
+        if (!ABL_L) { fb.load(lb, b_off, lane);
+        fa1.load(la, 32, lane); }
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 0)
         // ---- ph2: pair 1 (set 1)   | prefetch pair 2 -> set 0
-        if (t + 2 < nt) issueB(0, t + 2, b3n);
-        fa0.load(la, 64, lane);
+        if (t + 2 < nt) issueB(EARLY_B ? 1 : 0, t + 2, b3n);
+        if (!ABL_L) fa0.load(la, 64, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 2)
         // (no barrier: the B slots were released by ph1's barrier, nothing new has to be visible yet)
         // ---- ph3: pair 2 (set 0)   | prefetch pair 3 -> set 1
-        if (t + 2 < nt) issueB(1, t + 2, b3n);
-        fa1.load(la, 96, lane);
+        if (!EARLY_B && t + 2 < nt) issueB(1, t + 2, b3n);
+        if (!ABL_L) fa1.load(la, 96, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 4)
         WAIT_LGKM(0);                                           // pair-3 reads done: the A slots of this buffer are dead
         if (t + 2 < nt) { WAIT_VM(4); } else { WAIT_VM(0); }    // tile t+1 has landed
-        BARRIER();
+        if (!ABL_B) BARRIER();
         // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
-        if (t + 2 < nt) issueA(0, t + 2, b);
-        if (t + 1 < nt) fa0.load(slotA(b ^ 1, a_half), 0, lane);
+        if (t + 2 < nt) { issueA(0, t + 2, b); if (EARLY_A1) issueA(1, t + 2, b); }
+        if (!ABL_L && t + 1 < nt) fa0.load(slotA(b ^ 1, a_half), 0, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 6)
         // (no barrier: ph1(t+1) only touches slots ph3's barrier has already released / published)

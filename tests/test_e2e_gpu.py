@@ -157,6 +157,39 @@ def test_grad_accumulation_and_freeze(dev):
     assert float(m.grad_arena[o:o + n].abs().max()) > 0.0
 
 
+def test_ignore_index_padding(dev):
+    """Targets padded with IGNORE_INDEX (csm.data.collate_variable_length(target_pad=-100)): padded frames leave both
+    loss terms and the mean runs over labelled rows, as torch's cross_entropy(ignore_index=-100) does in the oracle."""
+    from csm.data.training_data import IGNORE_INDEX
+    from csm.training.utils import compute_loss
+    m, p32, pq = tiny_model(dev)
+    m.acoustic_mode = "all"
+    tokens, mask, targets = O.synthetic_batch(TINY, 3, 24, seed=11)
+    targets = targets.clone()
+    targets[0, 15:] = IGNORE_INDEX
+    targets[2, 7:] = IGNORE_INDEX
+    with pytest.raises(ValueError):
+        compute_loss(m, tokens, mask, targets)                     # negative labels are an error unless an ignore index is set
+    m.target_ignore_index = IGNORE_INDEX
+    m.ensure_grads()
+    total, det = compute_loss(m, tokens, mask, targets)
+    total.backward()
+    S = tokens.shape[1]
+    valid = (targets[:, :S - 1, 0] >= 0).reshape(-1).nonzero().squeeze(1)
+    pr = {k: v.clone().requires_grad_(True) for k, v in pq.items()}
+    rt, rdet = O.compute_loss(pr, TINY, tokens, mask, targets, acoustic_rows=valid)
+    rt.backward()
+    assert rel(total, rt) < 1e-3, (float(total), float(rt))
+    assert rel(det["semantic_loss"], rdet["semantic_loss"]) < 1e-3 and rel(det["acoustic_loss"], rdet["acoustic_loss"]) < 1e-3
+    grads = dict(m.named_parameters())
+    for k in ("codebook0_head.weight", "backbone.layers.0.attn.q_proj.weight", "decoder.layers.1.mlp.w2.weight", "projection.weight"):
+        gclose(k, grads[k].grad, pr[k].grad, 5e-2)
+    # the same batch with zero padding (reference behaviour) gives a different, larger-denominator loss
+    m.target_ignore_index = None
+    z, _ = compute_loss(m, tokens, mask, targets.clamp(min=0))
+    assert abs(float(z) - float(total)) > 1e-3
+
+
 def test_lora_step(dev):
     from csm.training.lora import apply_lora_to_model, merge_lora_weights
     from csm.training.utils import compute_loss

@@ -7,6 +7,8 @@ magnitude.  Codes are integers; a near-tie in the 2048-way nearest-codeword sear
 then changes the rest of that frame's residual chain, so the requirement is >= 97 % of frames identical in the semantic
 codebook and >= 90 % of all codes identical - plus exact equality when the GPU quantiser is fed HF's own latent.
 """
+import json
+
 import pytest
 import torch
 
@@ -87,3 +89,70 @@ def test_mimi_as_generator_tokenizer(dev):
     assert toks.shape == (14, 33) and bool(mask[:, :32].all()) and not bool(mask[:, 32].any())   # 13 frames + EOS frame
     audio = gen.generate("ok", 1, [seg], max_audio_length_ms=400)
     assert audio.dim() == 1 and audio.numel() % 1920 == 0 and audio.numel() > 0 and torch.isfinite(audio).all()
+    # EOS handling (reference generator.py:196-199): stop at the first all-zero frame, whatever the host's check cadence
+    script = [torch.randint(1, 2048, (1, 32), device="cuda", generator=torch.Generator("cuda").manual_seed(i)) for i in range(12)]
+    script[5] = torch.zeros(1, 32, dtype=torch.long, device="cuda")
+    script[9] = torch.zeros(1, 32, dtype=torch.long, device="cuda")
+    for every in (1, 4, 8, 64):
+        calls = []
+        m.generate_frame = lambda *a, _c=calls, **k: (_c.append(1), script[len(_c) - 1])[1]
+        got = {}
+        codec_decode = codec.decode
+        codec.decode = lambda c, _g=got: (_g.update(codes=c.clone()), codec_decode(c))[1]
+        out = gen.generate("ok", 1, [], max_audio_length_ms=12 * 80, eos_check_every=every)
+        codec.decode = codec_decode
+        assert got["codes"].shape == (1, 32, 5) and torch.equal(got["codes"][0].t(), torch.cat(script[:5], 0)), every
+        assert out.numel() == 5 * 1920
+    script[0] = torch.zeros(1, 32, dtype=torch.long, device="cuda")            # EOS at once -> empty audio
+    calls = []
+    m.generate_frame = lambda *a, _c=calls, **k: (_c.append(1), script[len(_c) - 1])[1]
+    assert gen.generate("ok", 1, [], max_audio_length_ms=800).numel() == 0
+    del m.generate_frame
+
+
+def test_cli_trains_from_raw_audio(dev, tmp_path, monkeypatch):
+    """csm-train --audio-dir/--transcript-dir: the reference's raw-data flow (cli/train.py:228-329) with a local Mimi
+    weights file and a local tokenizer directory: segmentation -> Mimi codes on the GPU -> frames -> one epoch."""
+    import wave
+    import numpy as np
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    import csm.training.trainer as T
+    from csm.cli import common, train as cli_train
+    from csm.models.model import ModelArgs
+    monkeypatch.setattr(T, "csm_1b_args", lambda: ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", 128256, 2051, 32))
+    # data: two recordings of 13 s / 6 s at 16 kHz (resampled to 24 kHz), transcripts, one alignment file
+    (tmp_path / "wav").mkdir(); (tmp_path / "txt").mkdir(); (tmp_path / "al").mkdir()
+    rng = np.random.default_rng(0)
+    for name, secs in (("a", 13), ("b", 6)):
+        x = (0.2 * rng.standard_normal(16000 * secs)).clip(-1, 1)
+        with wave.open(str(tmp_path / "wav" / f"{name}.wav"), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes((x * 32767).astype("<i2").tobytes())
+        (tmp_path / "txt" / f"{name}.txt").write_text("the quick brown fox " * (secs // 2))
+    words = [{"word": f"w{i}", "start": 0.5 * i, "end": 0.5 * i + 0.4} for i in range(12)]
+    (tmp_path / "al" / "b.json").write_text(json.dumps({"words": words}))
+    # tokenizers: seeded random Mimi weights (HF key names) and a character-level stand-in for the Llama-3 tokenizer files
+    save_file({k: v.contiguous() for k, v in _hf_model().state_dict().items()}, str(tmp_path / "mimi.safetensors"))
+    vocab = {"<s>": 0, "</s>": 1, "<unk>": 2}
+    vocab.update({c: 3 + i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz[]0123456789 ")})
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", "isolated")
+    PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>").save_pretrained(str(tmp_path / "tok"))
+
+    args = cli_train.parse_args(["--model-path", "", "--audio-dir", str(tmp_path / "wav"), "--transcript-dir", str(tmp_path / "txt"),
+                                 "--alignment-dir", str(tmp_path / "al"), "--mimi-weights", str(tmp_path / "mimi.safetensors"),
+                                 "--text-tokenizer", str(tmp_path / "tok"), "--speaker-id", "4", "--val-split", "0.34"])
+    train_ds, val_ds = common.load_datasets(args)
+    assert len(train_ds) == 2 and len(val_ds) == 1                       # a -> 2 windows (0-10 s, 8-13 s), b -> 1 aligned span
+    it = train_ds[0]
+    ids = it["input_tokens"][:, -1].tolist()
+    assert ids[0] == 0 and ids[-1] == 1 and ids[1:4] == [vocab["["], vocab["4"], vocab["]"]]   # <s> [4] ... </s> in column 32
+    assert it["target_audio_tokens"].shape == (125, 32) and int(it["target_audio_tokens"].max()) < 2048   # 10 s = 125 frames
+    assert val_ds[0]["target_audio_tokens"].shape[0] == int(np.ceil((5.9 * 24000) / 1920))
+    rc = cli_train.main(["--model-path", "", "--output-dir", str(tmp_path / "out"), "--audio-dir", str(tmp_path / "wav"),
+                         "--transcript-dir", str(tmp_path / "txt"), "--mimi-weights", str(tmp_path / "mimi.safetensors"),
+                         "--text-tokenizer", str(tmp_path / "tok"), "--epochs", "1", "--batch-size", "2", "--accumulation-steps", "1",
+                         "--num-workers", "0", "--val-split", "0.34", "--acoustic-mode", "all", "--ignore-padding", "--val-every", "1"])
+    assert rc == 0 and (tmp_path / "out" / "final_latest.pt").exists()
