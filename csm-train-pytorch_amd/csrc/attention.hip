@@ -14,8 +14,11 @@
 //                   ds_read_b64_tr_b16 on a [key][d] LDS image.
 //   dK/dV        :  S = Q K^T    (query on the register index, key on the lane)  -> dV^T and dK^T accumulate in
 //                   registers over every q-block and every q-head of the kv group; no atomics, deterministic.
-// LDS images: "row" image (16-B chunk c of row r at chunk c ^ (r & (HD/8-1))) for ds_read_b128 fragments,
-// "tr" image (32-B slot s of row r at s ^ swz(r)) for the transposed reads; both conflict-free.
+// LDS images: ONE layout serves both kinds of read of a 64 x HD tile: 32-B slot s of row r sits at slot s ^ swz(r)
+// (swz = (r>>1)&3 for HD 64, r&7 for HD 128).  ds_read_b128 row fragments (k along d) and ds_read_b64_tr_b16 transposed
+// fragments (k along the rows) are both bank-conflict-free on it (checked lane group by lane group against the gfx950
+// banking rules), so a tile that is needed in both forms - K in the dQ kernel, Q and dO in the dK/dV kernel - is
+// written to LDS once.
 #include "common.h"
 #include <math.h>
 
@@ -26,11 +29,11 @@ struct Img {
     static constexpr int ROWB = HD * 2;
     static constexpr int CPR = HD / 8;          // 16-B chunks per row
     static constexpr int BYTES = 64 * ROWB;     // one 64-row image
-    __device__ static __forceinline__ int row_off(int r, int c) { return r * ROWB + ((c ^ (r & (CPR - 1))) << 4); }
     __device__ static __forceinline__ int tr_off(int r, int slot) {
         const int sw = (HD == 64) ? ((r >> 1) & 3) : (r & 7);
         return r * ROWB + ((slot ^ sw) << 5);
     }
+    __device__ static __forceinline__ int row_off(int r, int c) { return tr_off(r, c >> 1) + ((c & 1) << 4); }   // 16-B chunk c
 };
 
 // global -> registers: 64 rows x HD starting at row r0 of a [S][ld] panel (rows clamped to S-1)
@@ -47,15 +50,14 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ P, int ld, 
     }
 }
 
-template <int HD, bool ROW, bool TR>
-__device__ __forceinline__ void tile_store(char* row_img, char* tr_img, const U4 (&reg)[HD / 32]) {
+template <int HD>
+__device__ __forceinline__ void tile_store(char* img, const U4 (&reg)[HD / 32]) {
     constexpr int CPR = HD / 8;
 #pragma unroll
     for (int i = 0; i < HD / 32; ++i) {
         const int idx = threadIdx.x + 256 * i;
         const int r = idx / CPR, c = idx % CPR;
-        if (ROW) *reinterpret_cast<U4*>(row_img + Img<HD>::row_off(r, c)) = reg[i];
-        if (TR) *reinterpret_cast<U4*>(tr_img + Img<HD>::tr_off(r, c >> 1) + ((c & 1) << 4)) = reg[i];
+        *reinterpret_cast<U4*>(img + Img<HD>::row_off(r, c)) = reg[i];
     }
 }
 
@@ -128,12 +130,11 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
                                                      const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                      int S, int H, int KV, float scale) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32;
-    constexpr int NIMG = BWD ? 3 : 2;
+    constexpr int NIMG = 2;
     using I = Img<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto k_row = [&](int st) { return smem + st * NIMG * I::BYTES; };
-    auto v_img = [&](int st) { return smem + st * NIMG * I::BYTES + I::BYTES; };      // fwd: V tr image; bwd: V row image
-    auto k_tr = [&](int st) { return smem + st * NIMG * I::BYTES + 2 * I::BYTES; };   // bwd only
+    auto k_img = [&](int st) { return smem + st * NIMG * I::BYTES; };                  // row frags (S^T) and, in dQ, tr frags (K^T)
+    auto v_img = [&](int st) { return smem + st * NIMG * I::BYTES + I::BYTES; };      // fwd: tr frags (V^T); dQ: row frags
 
     // 1-D grid, XCD-aware: workgroup ids are dealt round-robin over the 8 XCDs; the bijective remap below hands every
     // XCD a contiguous run of work items, ordered (batch, kv-head) pair -> q-head of the group -> q-block (heaviest
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
     U4 kreg[NST], vreg[NST];
     tile_load<HD>(Kp, ld, S, 0, kreg);
     tile_load<HD>(Vp, ld, S, 0, vreg);
-    tile_store<HD, true, BWD>(k_row(0), k_tr(0), kreg);
-    tile_store<HD, BWD, !BWD>(v_img(0), v_img(0), vreg);
+    tile_store<HD>(k_img(0), kreg);
+    tile_store<HD>(v_img(0), vreg);
     __syncthreads();
 
     for (int kb = 0; kb < nkb; ++kb) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
                 bf16x8 kfr[NKS], vfr[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    kfr[ks] = frag_row<HD>(k_row(st), 16 * kt, ks, lane);
+                    kfr[ks] = frag_row<HD>(k_img(st), 16 * kt, ks, lane);
                     if (BWD) vfr[ks] = frag_row<HD>(v_img(st), 16 * kt, ks, lane);
                 }
 #pragma unroll
@@ -291,15 +292,15 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    const bf16x8 vt = frag_tr<HD>(BWD ? k_tr(st) : v_img(st), dt, s2, lane);
+                    const bf16x8 vt = frag_tr<HD>(BWD ? k_img(st) : v_img(st), dt, s2, lane);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         if (active[qt]) o[qt][dt] = MFMA(vt, pf[qt][s2], o[qt][dt]);
                 }
         }
         if (kb + 1 < nkb) {
-            tile_store<HD, true, BWD>(k_row(st ^ 1), k_tr(st ^ 1), kreg);
-            tile_store<HD, BWD, !BWD>(v_img(st ^ 1), v_img(st ^ 1), vreg);
+            tile_store<HD>(k_img(st ^ 1), kreg);
+            tile_store<HD>(v_img(st ^ 1), vreg);
         }
         __syncthreads();
     }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // dK / dV: block = 64*KT keys of one (b, kv-head); wave = KT tiles of 16 keys; loops the q-heads of the group and the
-// q-blocks at or below the diagonal.  Q / dO tiles (row + transposed images) and the block's lse / delta are
+// q-blocks at or below the diagonal.  Q / dO tiles (one image each, read both ways) and the block's lse / delta are
 // double-buffered in LDS; one barrier per q-block.
 template <int HD, int KT>
 __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
@@ -338,13 +339,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
                                                           bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32, KB = 64 * KT;
     using I = Img<HD>;
-    constexpr int STAGE = 4 * I::BYTES + 512;
+    constexpr int STAGE = 2 * I::BYTES + 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto q_row = [&](int st) { return smem + st * STAGE; };
-    auto q_tr = [&](int st) { return smem + st * STAGE + I::BYTES; };
-    auto do_row = [&](int st) { return smem + st * STAGE + 2 * I::BYTES; };
-    auto do_tr = [&](int st) { return smem + st * STAGE + 3 * I::BYTES; };
-    auto stat = [&](int st) { return reinterpret_cast<float*>(smem + st * STAGE + 4 * I::BYTES); };  // [0..63] lse*log2e, [64..127] delta
+    auto q_img = [&](int st) { return smem + st * STAGE; };                    // row frags (S) and tr frags (dK)
+    auto do_img = [&](int st) { return smem + st * STAGE + I::BYTES; };        // row frags (dP) and tr frags (dV)
+    auto stat = [&](int st) { return reinterpret_cast<float*>(smem + st * STAGE + 2 * I::BYTES); };  // [0..63] lse*log2e, [64..127] delta
 
     // 1-D XCD-aware grid (see attn_q_kernel): contiguous run of (batch, kv-head) pairs per XCD, heaviest key block first
     const int nkblk = (S + KB - 1) / KB;
@@ -401,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
         }
     };
     auto commit = [&](int st) {
-        tile_store<HD, true, true>(q_row(st), q_tr(st), qreg);
-        tile_store<HD, true, true>(do_row(st), do_tr(st), dreg);
+        tile_store<HD>(q_img(st), qreg);
+        tile_store<HD>(do_img(st), dreg);
         if (threadIdx.x < 128) stat(st)[threadIdx.x] = streg;
     };
     if (niter > 0) { prefetch(0); commit(0); }
@@ -426,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
                 bf16x8 qfr[NKS], dofr[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    qfr[ks] = frag_row<HD>(q_row(st), 16 * qt, ks, lane);
-                    dofr[ks] = frag_row<HD>(do_row(st), 16 * qt, ks, lane);
+                    qfr[ks] = frag_row<HD>(q_img(st), 16 * qt, ks, lane);
+                    dofr[ks] = frag_row<HD>(do_img(st), 16 * qt, ks, lane);
                 }
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
@@ -462,8 +461,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    const bf16x8 dot = frag_tr<HD>(do_tr(st), dt, s2, lane);
-                    const bf16x8 qtt = frag_tr<HD>(q_tr(st), dt, s2, lane);
+                    const bf16x8 dot = frag_tr<HD>(do_img(st), dt, s2, lane);
+                    const bf16x8 qtt = frag_tr<HD>(q_img(st), dt, s2, lane);
 #pragma unroll
                     for (int t = 0; t < KT; ++t) {
                         if (!active[t]) continue;
@@ -531,7 +530,7 @@ static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
 template <int HD, bool BWD, int QT>
 static void launch_q(const void* qkv, void* out, float* lse, const void* dout, const float* delta, void* dqkv, int B, int S,
                      int H, int KV, float scale, hipStream_t stream) {
-    constexpr int lds = 2 * (BWD ? 3 : 2) * Img<HD>::BYTES;
+    constexpr int lds = 2 * 2 * Img<HD>::BYTES;
     auto k = attn_q_kernel<HD, BWD, QT>;
     static bool done = false;
     if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
@@ -544,7 +543,7 @@ static void launch_q(const void* qkv, void* out, float* lse, const void* dout, c
 template <int HD, int KT>
 static void launch_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
                        int KV, float scale, hipStream_t stream) {
-    constexpr int lds = 2 * (4 * Img<HD>::BYTES + 512);
+    constexpr int lds = 2 * (2 * Img<HD>::BYTES + 512);
     auto k = attn_dkv_kernel<HD, KT>;
     static bool done = false;
     if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
