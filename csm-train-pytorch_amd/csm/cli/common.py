@@ -32,7 +32,7 @@ class TokenFileDataset(Dataset):
         return collate_variable_length([self.items[(batch_idx * batch_size + j) % len(self.items)] for j in range(batch_size)])
 
 
-def add_data_args(parser):
+def add_data_args(parser, context_turns: int = 0):
     g = parser.add_argument_group("Data")
     g.add_argument("--token-file", type=str, default=None, help="torch.save'd list of tokenised examples")
     g.add_argument("--synthetic", type=int, default=0, help="use N seeded synthetic sequences instead of a token file")
@@ -44,7 +44,7 @@ def add_data_args(parser):
     g.add_argument("--speaker-id", type=int, default=0)
     g.add_argument("--mimi-weights", type=str, default=None, help="local Mimi weights (transformers.MimiModel state dict)")
     g.add_argument("--text-tokenizer", type=str, default=None, help="local directory of the Llama-3.2 tokenizer files")
-    g.add_argument("--context-turns", type=int, default=0, help="previous utterances of the same file given as context (reference: 0)")
+    g.add_argument("--context-turns", type=int, default=context_turns, help="previous utterances of the same file given as context")
     g.add_argument("--ignore-padding", action="store_true", help="pad targets with -100 so padded frames leave the loss")
 
 

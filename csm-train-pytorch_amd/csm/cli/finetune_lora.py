@@ -11,8 +11,7 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Fine-tune CSM with LoRA (MI355X)")
     p.add_argument("--model-path", type=str, required=True, help="checkpoint (.pt or .safetensors); '' = random init")
     p.add_argument("--output-dir", type=str, default="csm_lora")
-    add_data_args(p)
-    p.add_argument("--context-turns", type=int, default=2)
+    add_data_args(p, context_turns=2)   # reference default of csm-finetune-lora
     lo = p.add_argument_group("LoRA")
     lo.add_argument("--lora-r", type=int, default=8)
     lo.add_argument("--lora-alpha", type=float, default=16.0)

@@ -120,6 +120,13 @@ __device__ __forceinline__ float rows_sum(float x) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// experiment switches for tools/probes (never set in the shipped build): what bounds the dK/dV loop?
+// bit0: no global prefetch / LDS commit after the first tile; bit1: no softmax VALU work; bit2: no LDS fragment reads
+#ifndef CSM_ATT_ABLATE
+#define CSM_ATT_ABLATE 0
+#endif
+constexpr bool AAB_G = CSM_ATT_ABLATE & 1, AAB_V = CSM_ATT_ABLATE & 2, AAB_L = CSM_ATT_ABLATE & 4;
+
 // ------------------------------------------------------------------------------------------------
 // forward (BWD=false) and dQ (BWD=true) share one skeleton: block = 64*QT queries of one (b, h); wave = QT tiles of
 // 16 queries, so every K / V fragment read from LDS feeds QT MFMAs.  K/V tiles are double-buffered in LDS
@@ -128,7 +135,7 @@ template <int HD, bool BWD, int QT>
 __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, const bf16_t* __restrict__ dout,
                                                      const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                     int S, int H, int KV, float scale) {
+                                                     int S, int H, int KV, float scale, int lpt) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32;
     constexpr int NIMG = 2;
     using I = Img<HD>;
@@ -149,6 +156,14 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
         const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
         pair = nid / per_pair;
         local = nid % per_pair;
+        const int run = (xcd < r8) ? q8 + 1 : q8;
+        const int base = nid - within;
+        if (lpt && run % per_pair == 0 && base % per_pair == 0) {   // longest first over the whole run: q-block major, (pair, head) minor
+            const int ncomb = (run / per_pair) * rep_;
+            const int comb = within % ncomb;
+            pair = base / per_pair + comb / rep_;
+            local = (comb % rep_) * nqblk + within / ncomb;
+        }
     }
     const int qb = nqblk - 1 - (local % nqblk);
     const int kvh_ = pair % KV, b = pair / KV;
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float p = fast_exp2(fmaf(s[qt][kt][r], c2, nlse2[qt]));   // masked: exp2(-inf) = 0
-                            s[qt][kt][r] = p * (dp[qt][kt][r] - my_delta[qt]) * scale;  // dS^T
+                            s[qt][kt][r] = p * (dp[qt][kt][r] - my_delta[qt]);  // dS^T / scale (the factor goes on dQ below)
                         }
                 }
                 pf[qt][0] = frag_from_acc(s[qt][0], s[qt][1]);
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
             bf16_t* op = dqkv + ((size_t)b * S + qrow[qt]) * ld + h * HD;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                uint2 w; w.x = pack2bf(o[qt][dt][0], o[qt][dt][1]); w.y = pack2bf(o[qt][dt][2], o[qt][dt][3]);
+                uint2 w; w.x = pack2bf(o[qt][dt][0] * scale, o[qt][dt][1] * scale); w.y = pack2bf(o[qt][dt][2] * scale, o[qt][dt][3] * scale);
                 *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
             }
         }
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
 template <int HD, int KT>
 __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale) {
+                                                          bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale, int map) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32, KB = 64 * KT;
     using I = Img<HD>;
     constexpr int STAGE = 2 * I::BYTES + 512;
@@ -354,8 +369,21 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
         const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
         const int pair = nid / nkblk;
         kblk = nid % nkblk;
-        kvh = pair % KV;
-        b = pair / KV;
+        // Causal work falls linearly with the key block and the grid is one wave of workgroups (two per CU), so the
+        // two workgroups that share a CU should hold complementary key blocks.  map 1 assumes the dispatcher deals an
+        // XCD's workgroups breadth-first (w and w + run/2 share a CU), map 2 depth-first (w and w ^ 1 share a CU).
+        const int run = (xcd < r8) ? q8 + 1 : q8, half = run >> 1;
+        if (map == 1 && (run & 1) == 0 && half % nkblk == 0 && within >= half) kblk = nkblk - 1 - kblk;
+        if (map == 2 && (nkblk & 1) == 0 && (within & 1)) kblk = nkblk - 1 - (kblk ^ 1);
+        int pair_ = pair;
+        const int base = nid - within;
+        if (map == 3 && run % nkblk == 0 && base % nkblk == 0) {      // heaviest key blocks of every (b, kv-head) of the run first
+            const int npairs = run / nkblk;
+            kblk = within / npairs;
+            pair_ = base / nkblk + within % npairs;
+        }
+        kvh = pair_ % KV;
+        b = pair_ / KV;
     }
     const int rep = H / KV;
     const int ld = (H + 2 * KV) * HD, ldo = H * HD;
@@ -408,9 +436,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
     __syncthreads();
 
     for (int it = 0; it < niter; ++it) {
-        const int st = it & 1;
+        const int st = AAB_G ? 0 : (it & 1);
         const int qb = qb0 + it % per_head;
-        if (it + 1 < niter) prefetch(it + 1);
+        if (!AAB_G && it + 1 < niter) prefetch(it + 1);
         bool active[KT];
         bool any = false;
 #pragma unroll
@@ -439,13 +467,22 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
                         dp[t][qt] = MFMA(dofr[ks], vf[t][ks], dp[t][qt]);
                     }
                     // s[t][qt][r] = S[q = qb*64+16qt+4g+r][key = key[t]]
+                    if (!AAB_V) {
+                        // the causal / tail mask only bites on the diagonal q-tile and in the last q-block (wave-uniform
+                        // test); everywhere else an element costs fma + exp2 + sub + mul (dS is left unscaled: the
+                        // 1/sqrt(hd) factor is applied once to dK in the epilogue)
+                        const int qlo = qb * 64 + 16 * qt;
+                        const bool edge = (qlo < key0[t] + 16) || (qlo + 16 > S);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = qb * 64 + 16 * qt + 4 * g + r;
-                        float p = fast_exp2(fmaf(s[t][qt][r], c2, -lse4[r]));
-                        if (key[t] > q || q >= S) p = 0.f;
-                        s[t][qt][r] = p;
-                        dp[t][qt][r] = p * (dp[t][qt][r] - del4[r]) * scale;
+                        for (int r = 0; r < 4; ++r) {
+                            float p = fast_exp2(fmaf(s[t][qt][r], c2, -lse4[r]));
+                            if (edge) {
+                                const int q = qlo + 4 * g + r;
+                                if (key[t] > q || q >= S) p = 0.f;
+                            }
+                            s[t][qt][r] = p;
+                            dp[t][qt][r] = p * (dp[t][qt][r] - del4[r]);
+                        }
                     }
                 }
             }
@@ -471,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
                     }
                 }
         }
-        if (it + 1 < niter) commit(st ^ 1);
+        if (!AAB_G && it + 1 < niter) commit(st ^ 1);
         __syncthreads();
     }
     // dk[t][dt][r] = dK^T[d = 16dt + 4g + r][key = key[t]]
@@ -482,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
         bf16_t* vp = dqkv + ((size_t)b * S + key[t]) * ld + (H + KV + kvh) * HD;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            uint2 w; w.x = pack2bf(dk[t][dt][0], dk[t][dt][1]); w.y = pack2bf(dk[t][dt][2], dk[t][dt][3]);
+            uint2 w; w.x = pack2bf(dk[t][dt][0] * scale, dk[t][dt][1] * scale); w.y = pack2bf(dk[t][dt][2] * scale, dk[t][dt][3] * scale);
             *reinterpret_cast<uint2*>(kp + 16 * dt + 4 * g) = w;
             uint2 u; u.x = pack2bf(dv[t][dt][0], dv[t][dt][1]); u.y = pack2bf(dv[t][dt][2], dv[t][dt][3]);
             *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = u;
@@ -527,6 +564,7 @@ static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
     return 0;
 }
 
+static int g_attn_dkv_map = 3, g_attn_dkv_kt1 = 1, g_attn_q_lpt = 1;   // scheduling switches (csm_set_attn_variant)
 template <int HD, bool BWD, int QT>
 static void launch_q(const void* qkv, void* out, float* lse, const void* dout, const float* delta, void* dqkv, int B, int S,
                      int H, int KV, float scale, hipStream_t stream) {
@@ -537,7 +575,7 @@ static void launch_q(const void* qkv, void* out, float* lse, const void* dout, c
     done = true;
     dim3 grid((unsigned)(((S + 64 * QT - 1) / (64 * QT)) * H * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (const bf16_t*)dout, delta,
-                       (bf16_t*)dqkv, S, H, KV, scale);
+                       (bf16_t*)dqkv, S, H, KV, scale, g_attn_q_lpt);
 }
 
 template <int HD, int KT>
@@ -550,12 +588,19 @@ static void launch_dkv(const void* qkv, const void* dout, const float* lse, cons
     done = true;
     dim3 grid((unsigned)(((S + 64 * KT - 1) / (64 * KT)) * KV * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, S, H, KV,
-                       scale);
+                       scale, g_attn_dkv_map);
 }
 
 static int g_attn_qt = 1;   // query tiles per wave for the head_dim-64 forward / dQ kernels (tuning switch)
-extern "C" int csm_set_attn_variant(int qt) {
-    g_attn_qt = qt;
+extern "C" int csm_set_attn_variant(int v) {
+    // 0 restores the defaults.  Otherwise an experiment word: bits 0..3 query tiles per wave of the head_dim-64 forward /
+    // dQ kernels (1 | 2); bits 4..5 dK/dV work order (0 plain, 1 / 2 complementary pairing, 3 heaviest key blocks first);
+    // bit 6 dK/dV key tile (1: 64 keys per workgroup, 0: 128); bit 7 forward / dQ work order heaviest q-blocks first.
+    if (v == 0) v = 1 | (3 << 4) | (1 << 6) | (1 << 7);
+    g_attn_qt = v & 15;
+    g_attn_dkv_map = (v >> 4) & 3;
+    g_attn_dkv_kt1 = (v >> 6) & 1;
+    g_attn_q_lpt = (v >> 7) & 1;
     return 0;
 }
 
@@ -587,7 +632,8 @@ extern "C" int csm_attn_bwd(const void* qkv, const void* out, const void* dout, 
         CSM_CHECK_LAUNCH("csm_attn_bwd(delta)");
     }
     if (HD == 64) {
-        launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);   // KT=1 measured 15% slower
+        if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
         if (S > 64 && g_attn_qt == 2) launch_q<64, true, 2>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
         else launch_q<64, true, 1>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);

@@ -79,7 +79,8 @@ int csm_rope(void* qkv, const float* table, const int* pos, long long M, int S, 
 
 /* ---- K5: causal GQA attention replacing torchtune MultiHeadAttention -> F.scaled_dot_product_attention with the
  * mask of model.py:59-76 / training/utils.py:90-91.  qkv [B*S][(H+2KV)*HD]; out [B*S][H*HD]; lse [B][H][S]. */
-int csm_set_attn_variant(int query_tiles_per_wave); /* tuning switch: 1 (default) or 2, head_dim 64 only */
+int csm_set_attn_variant(int v); /* scheduling experiments: 0 = defaults; else bit fields (query tiles per wave, dK/dV key
+                                  * tile and work order, heaviest-first order of the forward / dQ grid) - see attention.hip */
 int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                  float* delta_ws /* [B][H][S] */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
