@@ -286,6 +286,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
     e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
+    if constexpr (sizeof(OutT) == 2) {
+        if (e.mode == EPI_SWIGLU_BWD) {
+            epi_swiglu_bwd_block<8, 4>(e, m0 + wr * 128, n0 + wc * 64, lane, acc);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + 16 * i + (lane & 15);

@@ -223,6 +223,44 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
     }
 }
 
+// SwiGLU-backward epilogue for a wave's NI x NJ block of 16x16 accumulators (rows mb + 16 i, d(act) columns nb + 16 j):
+// the gate/up vectors of TWO accumulator rows (2 * NJ 16-byte loads per lane) are fetched before any of their results is
+// stored - issued one by one between the stores they would sit behind every store's address check and the epilogue
+// would pay one full memory latency per accumulator.
+template <int NI, int NJ>
+__device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int nb, int lane, const f32x4 (&acc)[NI][NJ]) {
+    const int g = lane >> 4;
+    bf16_t* C = reinterpret_cast<bf16_t*>(e.C);
+#pragma unroll
+    for (int i = 0; i < NI; i += 2) {
+        U4 gu[2][NJ];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int m = mb + 16 * (i + ii) + (lane & 15), n = nb + 16 * j + 4 * g;
+                gu[ii][j] = (U4){0u, 0u, 0u, 0u};
+                if (m < e.M && n < e.N) gu[ii][j] = *reinterpret_cast<const U4*>(e.aux_in + (size_t)m * e.ld_aux + 2 * n);
+            }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int m = mb + 16 * (i + ii) + (lane & 15), n = nb + 16 * j + 4 * g;
+                float gv[8], o[8];
+                unpack8(gu[ii][j], gv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = acc[i + ii][j][k] * e.alpha, gt = gv[2 * k], up = gv[2 * k + 1];
+                    const float sg = 1.f / (1.f + __expf(-gt));
+                    o[2 * k] = v * up * sg * (1.f + gt * (1.f - sg));
+                    o[2 * k + 1] = v * gt * sg;
+                }
+                if (m < e.M && n < e.N) *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + 2 * n) = pack8(o);
+            }
+    }
+}
+
 // Two horizontally adjacent 16x16 accumulators (columns nb .. nb+31 of the same 16 rows) stored with 16-byte
 // accesses: v_permlane16_swap exchanges the odd 16-lane rows of the left tile with the even rows of the right tile, so
 // even lane-groups end up with 8 consecutive columns of the left tile and odd lane-groups with 8 of the right tile
@@ -234,8 +272,9 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
     const int g = lane >> 4;
     bool wide = false;
     if constexpr (sizeof(OutT) == 2)
-        wide = vec_ok && e.mode == EPI_NONE && (e.ldc & 7) == 0 && (!e.R || (e.ldr & 7) == 0) && nb + 31 < e.N &&
-               ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) && (!e.R || (reinterpret_cast<uintptr_t>(e.R) & 15) == 0);
+        wide = vec_ok && (e.mode == EPI_NONE || (e.mode == EPI_SWIGLU_FWD && (e.ld_aux & 3) == 0)) && (e.ldc & 7) == 0 &&
+               (!e.R || (e.ldr & 7) == 0) && nb + 31 < e.N && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) &&
+               (!e.R || (reinterpret_cast<uintptr_t>(e.R) & 15) == 0);
     if (!wide) {
         const int n = nb + 4 * g;
         if (m < e.M && n < e.N) epi_store<OutT>(e, vec_ok, m, n, a);
@@ -258,6 +297,13 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
         for (int k = 0; k < 8; ++k) v[k] += rr[k];
     }
     *reinterpret_cast<U4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = pack8(v);
+    if (e.mode == EPI_SWIGLU_FWD) {   // v = g0,u0,g1,u1,g2,u2,g3,u3 (gate / up interleaved along N): four activations, one 8-byte store
+        float a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = v[2 * k] / (1.f + __expf(-v[2 * k])) * v[2 * k + 1];
+        uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
+        *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
+    }
 }
 
 }  // namespace
