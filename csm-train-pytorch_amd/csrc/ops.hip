@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 }
 
 // dx = rstd * (dy*w) - x * rstd^3/D * sum(dy*w*x) (+ dres);  per-block partial of dw = sum_rows dy * x * rstd
+// One wave per row, 8 waves per block, one block per CU: all three row streams (x, dy, dres) are requested before the
+// reduction so 12 x 16 B per lane are in flight, instead of fetching dres after the row's dot product is known.
 template <int NC>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(512) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           const float* __restrict__ rstd, const bf16_t* __restrict__ dy,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                           float* __restrict__ dw_acc, int M, int D) {
@@ -62,33 +64,36 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int i = 0; i < NC; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dwl[i][j] = 0.f;
-    float ws[NC][8];
+    U4 wq[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         const int c = lane + 64 * i;
-        U4 t = {0u, 0u, 0u, 0u};
-        if (c < nchunk) t = *reinterpret_cast<const U4*>(w + c * 8);
-        unpack8(t, ws[i]);
+        wq[i] = (U4){0u, 0u, 0u, 0u};
+        if (c < nchunk) wq[i] = *reinterpret_cast<const U4*>(w + c * 8);
     }
     for (long long row = (long long)blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += (long long)gridDim.x * wpb) {
-        float xs[NC][8], gs[NC][8];
-        float dot = 0.f;
-        const float r = rstd[row];
+        U4 xa[NC], ga[NC], ra[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            U4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+            xa[i] = ga[i] = ra[i] = (U4){0u, 0u, 0u, 0u};
             if (c < nchunk) {
-                a = *reinterpret_cast<const U4*>(x + (size_t)row * D + c * 8);
-                b = *reinterpret_cast<const U4*>(dy + (size_t)row * D + c * 8);
+                xa[i] = *reinterpret_cast<const U4*>(x + (size_t)row * D + c * 8);
+                ga[i] = *reinterpret_cast<const U4*>(dy + (size_t)row * D + c * 8);
+                if (dres) ra[i] = *reinterpret_cast<const U4*>(dres + (size_t)row * D + c * 8);
             }
-            unpack8(a, xs[i]);
-            unpack8(b, gs[i]);
+        }
+        const float r = rstd[row];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            float xs[8], gs[8], ws[8];
+            unpack8(xa[i], xs); unpack8(ga[i], gs); unpack8(wq[i], ws);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (dw_acc) dwl[i][j] += gs[i][j] * xs[i][j] * r;
-                gs[i][j] *= ws[i][j];
-                dot += gs[i][j] * xs[i][j];
+                const float gx = gs[j] * xs[j];
+                if (dw_acc) dwl[i][j] += gx * r;
+                dot += gx * ws[j];
             }
         }
         dot = wave_sum(dot);
@@ -97,15 +102,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
             if (c < nchunk) {
-                float o[8];
+                float xs[8], gs[8], ws[8], rr[8], o[8];
+                unpack8(xa[i], xs); unpack8(ga[i], gs); unpack8(wq[i], ws); unpack8(ra[i], rr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = r * gs[i][j] - k * xs[i][j];
-                if (dres) {
-                    float rr[8];
-                    unpack8(*reinterpret_cast<const U4*>(dres + (size_t)row * D + c * 8), rr);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += rr[j];
-                }
+                for (int j = 0; j < 8; ++j) o[j] = r * (gs[j] * ws[j]) - k * xs[j] + rr[j];
                 *reinterpret_cast<U4*>(dx + (size_t)row * D + c * 8) = pack8(o);
             }
         }
@@ -131,19 +131,30 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
 }
 
-// dst(bf16)[col] (+)= sum_r partials[r][col]; block = 64 columns x 4 row slices (coalesced 256-B row reads)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partials, int rows, int D, bf16_t* __restrict__ dst,
-                                                     int accumulate) {
-    __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+// dst(bf16)[col] (+)= sum_r partials[r][col]; block = 64 columns x (blockDim.x / 64) row slices (coalesced 256-B row
+// reads): 4 slices for the few-row split-K slabs, 16 for the 256 per-block partial rows of the RMSNorm backward, where
+// only D / 64 blocks exist and the row loop is the whole latency.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partials, int rows, int D, bf16_t* __restrict__ dst,
+                                                      int accumulate) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ns = blockDim.x >> 6;
     const int col = blockIdx.x * 64 + c;
-    float t = 0.f;
-    if (col < D)
-        for (int r = sl; r < rows; r += 4) t += partials[(size_t)r * D + col];
-    red[sl][c] = t;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (col < D) {
+        int r = sl;
+        for (; r + 3 * ns < rows; r += 4 * ns) {
+            t0 += partials[(size_t)r * D + col];
+            t1 += partials[(size_t)(r + ns) * D + col];
+            t2 += partials[(size_t)(r + 2 * ns) * D + col];
+            t3 += partials[(size_t)(r + 3 * ns) * D + col];
+        }
+        for (; r < rows; r += ns) t0 += partials[(size_t)r * D + col];
+    }
+    red[sl][c] = (t0 + t1) + (t2 + t3);
     __syncthreads();
     if (sl == 0 && col < D) {
-        t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        float t = 0.f;
+        for (int k = 0; k < ns; ++k) t += red[k][c];
         if (accumulate) t += bf2f(dst[col]);
         dst[col] = f2bf(t);
     }
@@ -546,8 +557,13 @@ extern "C" int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rs
     CSM_REQUIRE(M > 0 && D > 0 && (D & 7) == 0 && D <= 4096, "csm_rmsnorm_bwd: D=%d must be a multiple of 8 and <= 4096", D);
     const int grid = CSM_RMSNORM_BWD_BLOCKS;
     const int nc = (D + 511) / 512;
-    const size_t lds = dscale_partials ? (size_t)4 * D * sizeof(float) : 0;
-#define L(NC) hipLaunchKernelGGL((rmsnorm_bwd_kernel<NC>), dim3(grid), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)scale, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dscale_partials, M, D)
+    const size_t lds = dscale_partials ? (size_t)8 * D * sizeof(float) : 0;      // 8 waves x D floats (64 KiB at D = 2048)
+    if (lds > 65536) {   // only the D > 2048 instance needs more than the default dynamic-LDS limit
+        static bool done = false;
+        if (!done) (void)hipFuncSetAttribute((const void*)rmsnorm_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * 4096 * sizeof(float)));
+        done = true;
+    }
+#define L(NC) hipLaunchKernelGGL((rmsnorm_bwd_kernel<NC>), dim3(grid), dim3(512), lds, stream, (const bf16_t*)x, (const bf16_t*)scale, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dscale_partials, M, D)
     if (nc <= 1) L(1); else if (nc <= 2) L(2); else if (nc <= 4) L(4); else L(8);
 #undef L
     CSM_CHECK_LAUNCH("csm_rmsnorm_bwd");
@@ -556,7 +572,8 @@ extern "C" int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rs
 
 extern "C" int csm_colsum_bf16(const float* partials, int rows, int D, void* dst, int accumulate, hipStream_t stream) {
     CSM_REQUIRE(partials && dst && rows > 0 && D > 0, "csm_colsum_bf16: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(256), 0, stream, partials, rows, D, (bf16_t*)dst, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(rows >= 64 ? 1024 : 256), 0, stream, partials, rows, D, (bf16_t*)dst,
+                       accumulate);
     CSM_CHECK_LAUNCH("csm_colsum_bf16");
     return 0;
 }
