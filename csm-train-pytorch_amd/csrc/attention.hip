@@ -134,7 +134,7 @@ constexpr bool AAB_G = CSM_ATT_ABLATE & 1, AAB_V = CSM_ATT_ABLATE & 2, AAB_L = C
 template <int HD, bool BWD, int QT>
 __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, const bf16_t* __restrict__ dout,
-                                                     const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                     float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                      int S, int H, int KV, float scale, int lpt) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32;
     constexpr int NIMG = 2;
@@ -190,7 +190,17 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
         if (BWD) {
             load_rowfrags<HD>(dout + (size_t)b * S * (H * HD) + h * HD, H * HD, qc, dof[qt], lane);
             nlse2[qt] = -lse[((size_t)b * H + h) * S + qc] * 1.4426950408889634f;
-            my_delta[qt] = delta[((size_t)b * H + h) * S + qc];
+            // delta = rowsum(dO * O) of this query: computed here from the same row fragments and published for the
+            // dK/dV kernel, which runs after this one (saves a separate pass over O and dO)
+            bf16x8 of[NKS];
+            load_rowfrags<HD>(out + (size_t)b * S * (H * HD) + h * HD, H * HD, qc, of, lane);
+            float dsum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum += bf2f((bf16_t)dof[qt][ks][j]) * bf2f((bf16_t)of[ks][j]);
+            my_delta[qt] = rows_sum(dsum);
+            if (g == 0 && qrow[qt] < S) delta[((size_t)b * H + h) * S + qrow[qt]] = my_delta[qt];
         }
     }
 
@@ -527,35 +537,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
     }
 }
 
-// delta[b,h,s] = sum_d dO * O   (one 16-lane group per (row, head))
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int S, int H, int HD) {
-    const long long gid = (long long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    const long long total = (long long)B * S * H;
-    const int sub = threadIdx.x & 15;
-    float acc = 0.f;
-    long long row = 0; int h = 0;
-    const bool ok = gid < total;
-    if (ok) {
-        row = gid / H; h = (int)(gid % H);
-        const bf16_t* o = out + (size_t)row * H * HD + h * HD;
-        const bf16_t* d = dout + (size_t)row * H * HD + h * HD;
-        for (int c = sub * 8; c < HD; c += 128) {
-            float a[8], bb[8];
-            unpack8(*reinterpret_cast<const U4*>(o + c), a);
-            unpack8(*reinterpret_cast<const U4*>(d + c), bb);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc += a[i] * bb[i];
-        }
-    }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (ok && sub == 0) {
-        const long long bidx = row / S, s = row % S;
-        delta[((size_t)bidx * H + h) * S + s] = acc;
-    }
-}
-
 }  // namespace
 
 static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
@@ -566,7 +547,7 @@ static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
 
 static int g_attn_dkv_map = 3, g_attn_dkv_kt1 = 1, g_attn_q_lpt = 1;   // scheduling switches (csm_set_attn_variant)
 template <int HD, bool BWD, int QT>
-static void launch_q(const void* qkv, void* out, float* lse, const void* dout, const float* delta, void* dqkv, int B, int S,
+static void launch_q(const void* qkv, void* out, float* lse, const void* dout, float* delta, void* dqkv, int B, int S,
                      int H, int KV, float scale, hipStream_t stream) {
     constexpr int lds = 2 * 2 * Img<HD>::BYTES;
     auto k = attn_q_kernel<HD, BWD, QT>;
@@ -591,13 +572,14 @@ static void launch_dkv(const void* qkv, const void* dout, const float* lse, cons
                        scale, g_attn_dkv_map);
 }
 
-static int g_attn_qt = 1;   // query tiles per wave for the head_dim-64 forward / dQ kernels (tuning switch)
+static int g_attn_qt_fwd = 2, g_attn_qt_bwd = 1;   // query tiles per wave of the head_dim-64 forward / dQ kernels
 extern "C" int csm_set_attn_variant(int v) {
-    // 0 restores the defaults.  Otherwise an experiment word: bits 0..3 query tiles per wave of the head_dim-64 forward /
-    // dQ kernels (1 | 2); bits 4..5 dK/dV work order (0 plain, 1 / 2 complementary pairing, 3 heaviest key blocks first);
+    // 0 restores the defaults.  Otherwise an experiment word: bits 0..1 / 2..3 query tiles per wave of the head_dim-64
+    // forward / dQ kernel (1 | 2; 0 = 1); bits 4..5 dK/dV work order (0 plain, 1 / 2 complementary pairing, 3 heaviest key blocks first);
     // bit 6 dK/dV key tile (1: 64 keys per workgroup, 0: 128); bit 7 forward / dQ work order heaviest q-blocks first.
-    if (v == 0) v = 1 | (3 << 4) | (1 << 6) | (1 << 7);
-    g_attn_qt = v & 15;
+    if (v == 0) v = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7);
+    g_attn_qt_fwd = (v & 3) == 2 ? 2 : 1;
+    g_attn_qt_bwd = ((v >> 2) & 3) == 2 ? 2 : 1;
     g_attn_dkv_map = (v >> 4) & 3;
     g_attn_dkv_kt1 = (v >> 6) & 1;
     g_attn_q_lpt = (v >> 7) & 1;
@@ -610,7 +592,7 @@ extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S
     CSM_REQUIRE(qkv && out && lse, "csm_attn_fwd: null pointer");
     const float scale = 1.f / sqrtf((float)HD);
     if (HD == 64) {
-        if (S > 64 && g_attn_qt == 2) launch_q<64, false, 2>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
+        if (S > 64 && g_attn_qt_fwd == 2) launch_q<64, false, 2>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
         else launch_q<64, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
     } else {
         launch_q<128, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
@@ -624,24 +606,20 @@ extern "C" int csm_attn_bwd(const void* qkv, const void* out, const void* dout, 
     if (int e = check_attn("csm_attn_bwd", B, S, H, KV, HD)) return e;
     CSM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, "csm_attn_bwd: null pointer");
     const float scale = 1.f / sqrtf((float)HD);
-    {
-        const long long total = (long long)B * S * H;
-        const int per_block = 256 / 16;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0, stream,
-                           (const bf16_t*)out, (const bf16_t*)dout, delta_ws, B, S, H, HD);
-        CSM_CHECK_LAUNCH("csm_attn_bwd(delta)");
-    }
+    // dQ first: it also writes delta = rowsum(dO * O), which the dK/dV kernel reads
+    void* o = const_cast<void*>(out);
+    float* l = const_cast<float*>(lse);
     if (HD == 64) {
+        if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        else launch_q<64, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
         if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
         else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
-        CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
-        if (S > 64 && g_attn_qt == 2) launch_q<64, true, 2>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
-        else launch_q<64, true, 1>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
     } else {
+        launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
         launch_dkv<128, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
-        CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
-        launch_q<128, true, 1>(qkv, nullptr, const_cast<float*>(lse), dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
     }
-    CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
+    CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
     return 0;
 }

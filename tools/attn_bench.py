@@ -21,7 +21,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
-for v in [int(x) for x in os.environ.get('AB_VARIANTS', '1,241,1,241').split(',')]:
+for v in [int(x) for x in os.environ.get('AB_VARIANTS', '5,0,5,0').split(',')]:
     ops.lib.csm_set_attn_variant(v)
     tf = timeit(lambda: ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd))
     tb = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, dqkv, delta, B, S, H, KV, hd))
