@@ -437,23 +437,26 @@ class Engine:
         K, V = a.audio_num_codebooks, a.audio_vocab_size
         from .models.model import sample_topk
 
+        # all Exp(1) draws of the frame in one launch (the reference draws them one codebook at a time, model.py:79-82)
+        B = last_h.shape[0]
+        qall = None if noise is not None else torch.empty(K, B, V, dtype=F32, device=dev).exponential_(1)
+
         def draw(lg, i):
-            q = None if noise is None else noise[i].to(dev)
+            q = qall[i] if noise is None else noise[i].to(dev)
             return sample_topk(lg[:, :V], topk, temperature, q)
 
         ops.gemv(last_h, m.block("codebook0_head.padded"), st.logits)
-        c0 = draw(st.logits, 0)
-        samples = [c0]
-        aemb = m.block("audio_embeddings.weight")
-        x_in = last_h
+        samples = [draw(st.logits, 0)]
+        dnorm = m.block("decoder.norm.scale")
         for i in range(K):
-            # decoder position i: input = backbone state (i = 0) or the embedding of code i-1
-            hdec = st.decoder_step(x_in, i)
+            # decoder position i: input = backbone state (i = 0) or the embedding of code i-1; the stack's final norm is
+            # applied inside the head product (position 0 has no head)
+            hres = (st.decoder_step(last_h, i, final_norm=False) if i == 0 else
+                    st.decoder_step(None, i, code=samples[-1].view(-1), final_norm=False))
             if i >= 1:
-                ops.gemv(hdec, st.head_t[i - 1], st.logits)      # [V][d'] copy of audio_head[i-1]: row-per-wave GEMV
+                # [V][d'] copy of audio_head[i-1]: row-per-wave GEMV
+                ops.gemv_ex(hres, st.head_t[i - 1], st.logits, norm_scale=dnorm, eps=m.dc.norm_eps)
                 samples.append(draw(st.logits, i))
-            if i < K - 1:
-                x_in = aemb[samples[-1].long().view(-1) + i * V]
         return torch.cat(samples, dim=1)
 
     @torch.no_grad()
@@ -525,24 +528,25 @@ class _DecodeStack:
             self.k[i][:, :, :S] = qkv[:, :, H * hd:(H + KV) * hd].reshape(B, S, KV, hd).permute(0, 2, 1, 3)
             self.v[i][:, :, :S] = qkv[:, :, (H + KV) * hd:].reshape(B, S, KV, hd).permute(0, 2, 1, 3)
 
-    def step(self, x: torch.Tensor) -> torch.Tensor:
-        """One position per batch row at ``self.pos`` (device int32).  x [B, d] -> final-normed hidden [B, d]."""
+    def step(self, x: torch.Tensor, final_norm: bool = True) -> torch.Tensor:
+        """One position per batch row at ``self.pos`` (device int32).  x [B, d] -> final-normed hidden [B, d]
+        (``final_norm=False``: the un-normed residual stream, for a caller that fuses the norm into its next product)."""
         st, c = self.stack, self.stack.c
         H, KV, hd = c.num_heads, c.num_kv_heads, c.head_dim
         table = st.m.rope_table(st.prefix)
         cur, nxt = x, self.xa
         for i in range(c.num_layers):
-            ops.rmsnorm_fwd(cur, st.w(f"layers.{i}.sa_norm.scale"), self.xn, None, c.norm_eps)
-            ops.gemv(self.xn, st.w(f"layers.{i}.attn.qkv"), self.qkv)
-            ops.rope(self.qkv, table, 1, H + KV, hd, pos=self.pos)
-            ops.kv_append(self.qkv, self.k[i], self.v[i], self.pos, H, KV, hd)
-            ops.attn_decode(self.qkv, self.k[i], self.v[i], self.o, self.pos, H, KV, hd)
+            # five launches per layer: the norms ride in the prologue of the following matrix-vector product, RoPE and
+            # the cache append inside the attention kernel, SwiGLU in the epilogue of the w13 product
+            ops.gemv_ex(cur, st.w(f"layers.{i}.attn.qkv"), self.qkv, norm_scale=st.w(f"layers.{i}.sa_norm.scale"), eps=c.norm_eps)
+            ops.attn_decode_rope(self.qkv, self.k[i], self.v[i], self.o, self.pos, table, H, KV, hd)
             ops.gemv(self.o, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, residual=cur)
-            ops.rmsnorm_fwd(self.h, st.w(f"layers.{i}.mlp_norm.scale"), self.hn, None, c.norm_eps)
-            ops.gemv(self.hn, st.w(f"layers.{i}.mlp.w13"), self.gu)
-            ops.swiglu_fwd(self.gu, self.act)
+            ops.gemv_ex(self.h, st.w(f"layers.{i}.mlp.w13"), self.act, norm_scale=st.w(f"layers.{i}.mlp_norm.scale"), eps=c.norm_eps,
+                        swiglu=True)
             ops.gemv(self.act, st.w(f"layers.{i}.mlp.w2.weight"), nxt, residual=self.h)
             cur, nxt = nxt, (self.xb if nxt is self.xa else self.xa)
+        if not final_norm:
+            return cur
         ops.rmsnorm_fwd(cur, st.w("norm.scale"), self.xf, None, c.norm_eps)
         return self.xf
 
@@ -626,8 +630,14 @@ class DecodeState:
     def decoder_reset(self):
         pass   # positions restart at 0 every frame; stale cache rows beyond the current position are never read
 
-    def decoder_step(self, x_in, i):
+    def decoder_step(self, x_in, i, code=None, final_norm=True):
+        """Decoder position i.  Input = ``x_in`` [B, d] (the backbone state, i = 0) or, with ``code`` (int32 [B] on the
+        device), the audio embedding of code i-1 gathered inside the projection product (model.py:189-191)."""
         m = self.e.m
-        ops.gemv(x_in.contiguous(), m.block("projection.weight"), self.proj)
+        if code is None:
+            ops.gemv(x_in.contiguous(), m.block("projection.weight"), self.proj)
+        else:
+            ops.gemv_ex(m.block("audio_embeddings.weight"), m.block("projection.weight"), self.proj, row_index=code,
+                        row_offset=(i - 1) * m.args.audio_vocab_size)
         self.dc.pos = self.dpos[i]
-        return self.dc.step(self.proj)
+        return self.dc.step(self.proj, final_norm=final_norm)

@@ -250,6 +250,30 @@ def gemv(x, W, y, residual=None):
     return y
 
 
+def gemv_ex(x, W, y, residual=None, norm_scale=None, eps=1e-5, swiglu=False, row_index=None, row_offset=0):
+    """gemv with an RMSNorm prologue on x (norm_scale), the SwiGLU pairing of interleaved gate/up rows (y is [B, N/2]) and /
+    or x gathered from a table: batch row b = x[row_index[b] + row_offset] (row_index int32 [B] on the device)."""
+    B = y.shape[0]
+    K = x.shape[1]
+    N = W.shape[0]
+    assert W.shape[1] == K and y.shape == (B, N // 2 if swiglu else N) and x.stride(1) == 1 and W.stride(1) == 1 and y.stride(1) == 1
+    assert row_index is not None or x.shape[0] == B
+    assert row_index is None or (row_index.dtype == torch.int32 and row_index.numel() == B and row_index.is_contiguous())
+    check(lib.csm_gemv_bf16_ex(x.data_ptr(), W.data_ptr(), y.data_ptr(), _ptr(residual), B, N, K, W.stride(0), x.stride(0),
+                               y.stride(0), int(y.dtype == torch.float32), _ptr(norm_scale), float(eps), int(swiglu),
+                               _ptr(row_index), int(row_offset), _stream()), "csm_gemv_bf16_ex")
+    return y
+
+
+def attn_decode_rope(qkv, kcache, vcache, out, pos_i32, table, H, KV, HD):
+    """rope(q, new k) + append(new k, v) + one-position attention against the caches, one launch."""
+    B, _, S_max, _ = kcache.shape
+    assert table.dtype == torch.float32 and table.is_contiguous()
+    check(lib.csm_attn_decode_rope(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), pos_i32.data_ptr(),
+                                   table.data_ptr(), B, H, KV, HD, S_max, qkv.stride(0), _stream()), "csm_attn_decode_rope")
+    return out
+
+
 def gemv_t(x, W, y):
     """y[B,N] = x[B,K] W[K,N], B <= 4."""
     B, K = x.shape

@@ -50,20 +50,34 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         val[j] = c < V ? x[c] / temperature : -INFINITY;
         removed[j] = c >= V;
     }
-    // k-th largest by removing one maximum per round (ties are distinct elements, as in torch.topk)
-    float kth = -INFINITY, top = -INFINITY;
-    for (int k = 0; k < topk; ++k) {
-        ValIdx best = {-INFINITY, 0x7fffffff};
+    // k-th largest value (ties count as distinct elements, as in torch.topk) by bisection on an order-preserving integer
+    // image of the floats: 32 rounds of "how many keys are >= trial", each one block-wide count - instead of removing
+    // one maximum per round for k rounds.
+    uint32_t key[SMP_PER_THREAD];
+    float tmax = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < SMP_PER_THREAD; ++j)
-            if (!removed[j]) best = vi_max(best, (ValIdx){val[j], (int)threadIdx.x + 256 * j});
-        best = block_arg<true>(best, red);
-        if (k == 0) top = best.v;
-        kth = best.v;
-#pragma unroll
-        for (int j = 0; j < SMP_PER_THREAD; ++j)
-            if ((int)threadIdx.x + 256 * j == best.i) removed[j] = true;
+    for (int j = 0; j < SMP_PER_THREAD; ++j) {
+        const uint32_t u = __float_as_uint(val[j]);
+        key[j] = removed[j] ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+        tmax = fmaxf(tmax, val[j]);
     }
+    const float top = block_max(tmax, fred);
+    __shared__ int cnt_s[4];
+    uint32_t prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t trial = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < SMP_PER_THREAD; ++j) c += key[j] >= trial ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) cnt_s[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3] >= topk) prefix = trial;
+    }
+    const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    const float kth = __uint_as_float(ku);
     // log_softmax over kept values, then softmax of that (torch evaluates both)
     float s = 0.f;
 #pragma unroll
@@ -181,39 +195,85 @@ extern "C" int csm_rvq_decode(const long long* codes, const float* codebooks, fl
 namespace {
 
 // y[b][n] = sum_k x[b][k] * W[n][k] (+ R[b][n]);  one wave per output row, NB <= 4 batch rows share every weight load.
-template <int NB, typename OutT>
+// Two optional fusions remove the tiny kernels that otherwise sit between the matrix-vector products of a decode step:
+//   norm_w != NULL : x is RMS-normalised on its way into LDS (same arithmetic and summation order as rmsnorm_fwd_kernel:
+//                    one wave per row, lane-strided chunks, wave_sum, one rounding of x * rstd * w to bf16);
+//   SWIGLU         : W holds gate/up rows interleaved (w13); a wave computes rows 2i and 2i+1 and writes
+//                    y[b][i] = silu(g) * u with g, u rounded to bf16 first (what swiglu_fwd_kernel reads back);
+//   row_index      : batch row b of x is row (row_index[b] + row_offset) of a table (the embedding of a sampled code).
+template <int NB, typename OutT, bool SWIGLU>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
-                                                   const bf16_t* __restrict__ R, int N, int K, int ldw, int ldx, int ldy) {
+                                                   const bf16_t* __restrict__ R, int N, int K, int ldw, int ldx, int ldy,
+                                                   const bf16_t* __restrict__ norm_w, float eps, const int* __restrict__ row_index,
+                                                   int row_offset) {
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem_x);            // [NB][K]
+    __shared__ float rs[4];
     for (int i = threadIdx.x * 8; i < NB * K; i += blockDim.x * 8) {
         const int b = i / K, k = i - b * K;
-        *reinterpret_cast<U4*>(xs + i) = *reinterpret_cast<const U4*>(x + (size_t)b * ldx + k);
+        const size_t row = row_index ? (size_t)(row_index[b] + row_offset) : (size_t)b;   // x = table[index[b] + offset]: embedding lookup
+        *reinterpret_cast<U4*>(xs + i) = *reinterpret_cast<const U4*>(x + row * ldx + k);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    for (int n = blockIdx.x * wpb + (threadIdx.x >> 6); n < N; n += gridDim.x * wpb) {
-        float acc[NB];
+    if (norm_w) {
+        const int wv = threadIdx.x >> 6;
+        if (wv < NB) {
+            float ss = 0.f;
+            for (int c = lane; c < (K >> 3); c += 64) {
+                float f[8];
+                unpack8(*reinterpret_cast<const U4*>(xs + wv * K + c * 8), f);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-        const bf16_t* w = W + (size_t)n * ldw;
+                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) rs[wv] = rsqrtf(ss / (float)K + eps);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x * 8; i < NB * K; i += blockDim.x * 8) {
+            const int b = i / K, k = i - b * K;
+            float f[8], w8[8];
+            unpack8(*reinterpret_cast<const U4*>(xs + i), f);
+            unpack8(*reinterpret_cast<const U4*>(norm_w + k), w8);
+            const float r = rs[b];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = f[j] * r * w8[j];
+            *reinterpret_cast<U4*>(xs + i) = pack8(f);
+        }
+        __syncthreads();
+    }
+    constexpr int RW = SWIGLU ? 2 : 1;                          // weight rows per output
+    const int NO = N / RW;
+    for (int n = blockIdx.x * wpb + (threadIdx.x >> 6); n < NO; n += gridDim.x * wpb) {
+        float acc[RW][NB];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+        const bf16_t* w = W + (size_t)n * RW * ldw;
         for (int k = lane * 8; k < K; k += 512) {
-            float wf[8];
-            unpack8(*reinterpret_cast<const U4*>(w + k), wf);
+            float wf[RW][8];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) unpack8(*reinterpret_cast<const U4*>(w + (size_t)r * ldw + k), wf[r]);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float xf[8];
                 unpack8(*reinterpret_cast<const U4*>(xs + b * K + k), xf);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[b] += wf[j] * xf[j];
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][b] += wf[r][j] * xf[j];
             }
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float s = wave_sum(acc[b]);
+            float v = wave_sum(acc[0][b]);
+            if constexpr (SWIGLU) {
+                const float g = bf2f(f2bf(v)), u = bf2f(f2bf(wave_sum(acc[1][b])));
+                v = g / (1.f + __expf(-g)) * u;
+            }
             if (lane == 0) {
-                float v = s;
                 if (R) v += bf2f(R[(size_t)b * ldy + n]);
                 if constexpr (sizeof(OutT) == 2) y[(size_t)b * ldy + n] = f2bf(v);
                 else y[(size_t)b * ldy + n] = v;
@@ -268,33 +328,62 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 }
 
 // one query position against the cache: block per (b, q-head); scores for <= 2048 keys live in LDS.
+// table != NULL fuses what used to be two more launches per layer: the new position's q and k heads are rotated here
+// (torchtune RoPE on interleaved pairs, same arithmetic and bf16 rounding as rope_kernel), and the first q-head block of
+// every kv group appends the rotated k and the v of the new position to the caches.  Every block takes the new key /
+// value from the qkv row, not from the cache, so blocks of one group do not race with the appending block.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
-                                                          const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
+                                                          bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
                                                           const int* __restrict__ pos, int H, int KV, int S_max, int ld,
-                                                          float scale) {
+                                                          float scale, const float* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) char smem_a[];
     float* sc = reinterpret_cast<float*>(smem_a);                 // [S_max] scores, then probabilities
     float* red = sc + S_max;                                       // 16 floats
     float* part = red + 16;                                        // [4 waves][HD] partial outputs
+    float* qs = part + 4 * HD;                                     // [HD] query (rotated), bf16-rounded values
+    float* kn = qs + HD;                                           // [HD] new key (rotated)
     const int h = blockIdx.x, b = blockIdx.y;
-    const int kvh = h / (H / KV);
-    const int n = pos[b] + 1;                                      // keys 0 .. pos (the new one was appended already)
+    const int rep = H / KV, kvh = h / rep;
+    const int p = pos[b];
+    const int n = p + 1;                                           // keys 0 .. pos
     const bf16_t* q = qkv + (size_t)b * ld + h * HD;
-    const bf16_t* K = kc + ((size_t)b * KV + kvh) * S_max * HD;
-    const bf16_t* V = vc + ((size_t)b * KV + kvh) * S_max * HD;
+    const bf16_t* knew = qkv + (size_t)b * ld + (H + kvh) * HD;
+    const bf16_t* vnew = qkv + (size_t)b * ld + (H + KV + kvh) * HD;
+    bf16_t* K = kc + ((size_t)b * KV + kvh) * S_max * HD;
+    bf16_t* V = vc + ((size_t)b * KV + kvh) * S_max * HD;
+    if (threadIdx.x < HD / 2) {
+        const int i = threadIdx.x;
+        float c = 1.f, sn = 0.f;
+        if (table) { c = table[((size_t)p * (HD / 2) + i) * 2]; sn = table[((size_t)p * (HD / 2) + i) * 2 + 1]; }
+        const float q0 = bf2f(q[2 * i]), q1 = bf2f(q[2 * i + 1]), k0 = bf2f(knew[2 * i]), k1 = bf2f(knew[2 * i + 1]);
+        const bf16_t rq0 = f2bf(q0 * c - q1 * sn), rq1 = f2bf(q1 * c + q0 * sn);
+        const bf16_t rk0 = f2bf(k0 * c - k1 * sn), rk1 = f2bf(k1 * c + k0 * sn);
+        qs[2 * i] = bf2f(rq0); qs[2 * i + 1] = bf2f(rq1);
+        kn[2 * i] = bf2f(rk0); kn[2 * i + 1] = bf2f(rk1);
+        if (table && h % rep == 0) {
+            K[(size_t)p * HD + 2 * i] = rk0; K[(size_t)p * HD + 2 * i + 1] = rk1;
+            V[(size_t)p * HD + 2 * i] = vnew[2 * i]; V[(size_t)p * HD + 2 * i + 1] = vnew[2 * i + 1];
+        }
+    }
+    __syncthreads();
     float qf[HD];
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) unpack8(*reinterpret_cast<const U4*>(q + c * 8), qf + c * 8);
+    for (int c = 0; c < HD; ++c) qf[c] = qs[c];
     float mx = -INFINITY;
     for (int s = threadIdx.x; s < n; s += blockDim.x) {
         float d = 0.f;
+        if (s == p) {
 #pragma unroll
-        for (int c = 0; c < HD / 8; ++c) {
-            float kf[8];
-            unpack8(*reinterpret_cast<const U4*>(K + (size_t)s * HD + c * 8), kf);
+            for (int c = 0; c < HD; ++c) d += qf[c] * kn[c];
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d += qf[c * 8 + j] * kf[j];
+            for (int c = 0; c < HD / 8; ++c) {
+                float kf[8];
+                unpack8(*reinterpret_cast<const U4*>(K + (size_t)s * HD + c * 8), kf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += qf[c * 8 + j] * kf[j];
+            }
         }
         d *= scale;
         sc[s] = d;
@@ -315,7 +404,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int s = grp; s < n; s += ngrp) {
         float vf[8];
-        unpack8(*reinterpret_cast<const U4*>(V + (size_t)s * HD + sub * 8), vf);
+        unpack8(*reinterpret_cast<const U4*>((s == p ? vnew : V + (size_t)s * HD) + sub * 8), vf);
         const float p = sc[s];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += p * vf[j];
@@ -339,19 +428,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 
 }  // namespace
 
-extern "C" int csm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw,
-                             int ldx, int ldy, int out_f32, hipStream_t stream) {
+static int gemv_launch(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
+                       int out_f32, const void* norm_w, float eps, int swiglu, const int* row_index, int row_offset,
+                       hipStream_t stream) {
     CSM_REQUIRE(x && W && y && B >= 1 && B <= 4 && N > 0 && K > 0 && (K & 7) == 0 && (ldw & 7) == 0 && (ldx & 7) == 0,
                 "csm_gemv_bf16: bad arguments (B=%d N=%d K=%d)", B, N, K);
     CSM_REQUIRE((size_t)B * K * 2 <= 65536, "csm_gemv_bf16: B*K too large for the LDS copy of x");
-    const int grid = N / 4 < 1 ? 1 : (N / 4 > 2048 ? 2048 : N / 4);
+    CSM_REQUIRE(!swiglu || ((N & 1) == 0 && !out_f32), "csm_gemv_bf16_ex: the SwiGLU form needs an even N and bf16 output");
+    const int no = swiglu ? N / 2 : N;
+    const int grid = no / 4 < 1 ? 1 : (no / 4 > 2048 ? 2048 : no / 4);
     const size_t lds = (size_t)B * K * 2;
-#define L(NB, T) hipLaunchKernelGGL((gemv_kernel<NB, T>), dim3(grid), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, K, ldw, ldx, ldy)
-    if (out_f32) { if (B == 1) L(1, float); else if (B == 2) L(2, float); else if (B == 3) L(3, float); else L(4, float); }
-    else { if (B == 1) L(1, bf16_t); else if (B == 2) L(2, bf16_t); else if (B == 3) L(3, bf16_t); else L(4, bf16_t); }
+#define L(NB, T, SW) hipLaunchKernelGGL((gemv_kernel<NB, T, SW>), dim3(grid), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, K, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset)
+    if (swiglu) { if (B == 1) L(1, bf16_t, true); else if (B == 2) L(2, bf16_t, true); else if (B == 3) L(3, bf16_t, true); else L(4, bf16_t, true); }
+    else if (out_f32) { if (B == 1) L(1, float, false); else if (B == 2) L(2, float, false); else if (B == 3) L(3, float, false); else L(4, float, false); }
+    else { if (B == 1) L(1, bf16_t, false); else if (B == 2) L(2, bf16_t, false); else if (B == 3) L(3, bf16_t, false); else L(4, bf16_t, false); }
 #undef L
     CSM_CHECK_LAUNCH("csm_gemv_bf16");
     return 0;
+}
+
+extern "C" int csm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw,
+                             int ldx, int ldy, int out_f32, hipStream_t stream) {
+    return gemv_launch(x, W, y, residual, B, N, K, ldw, ldx, ldy, out_f32, nullptr, 0.f, 0, nullptr, 0, stream);
+}
+
+extern "C" int csm_gemv_bf16_ex(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw,
+                                int ldx, int ldy, int out_f32, const void* norm_scale, float eps, int swiglu, const int* row_index,
+                                int row_offset, hipStream_t stream) {
+    return gemv_launch(x, W, y, residual, B, N, K, ldw, ldx, ldy, out_f32, norm_scale, eps, swiglu, row_index, row_offset, stream);
 }
 
 extern "C" int csm_gemv_t_bf16(const void* x, const void* W, void* y, int B, int N, int K, int ldw, int ldx, int ldy,
@@ -375,19 +479,31 @@ extern "C" int csm_kv_append(const void* qkv, void* kcache, void* vcache, const 
     return 0;
 }
 
-extern "C" int csm_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* out, const int* pos, int B, int H,
-                               int KV, int HD, int S_max, int ld, hipStream_t stream) {
+static int attn_decode_launch(const void* qkv, void* kcache, void* vcache, void* out, const int* pos, const float* table, int B,
+                              int H, int KV, int HD, int S_max, int ld, hipStream_t stream) {
     CSM_REQUIRE(qkv && kcache && vcache && out && pos && B > 0 && H > 0 && KV > 0 && H % KV == 0, "csm_attn_decode: bad arguments");
     CSM_REQUIRE(HD == 64 || HD == 128, "csm_attn_decode: head_dim %d unsupported", HD);
     CSM_REQUIRE(S_max <= 8192, "csm_attn_decode: S_max too large");
-    const size_t lds = (size_t)(S_max + 16 + 4 * HD) * sizeof(float);
+    const size_t lds = (size_t)(S_max + 16 + 6 * HD) * sizeof(float);
     const float scale = 1.f / sqrtf((float)HD);
     if (HD == 64)
-        hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(H, B), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)kcache,
-                           (const bf16_t*)vcache, (bf16_t*)out, pos, H, KV, S_max, ld, scale);
+        hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(H, B), dim3(256), lds, stream, (const bf16_t*)qkv, (bf16_t*)kcache,
+                           (bf16_t*)vcache, (bf16_t*)out, pos, H, KV, S_max, ld, scale, table);
     else
-        hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(H, B), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)kcache,
-                           (const bf16_t*)vcache, (bf16_t*)out, pos, H, KV, S_max, ld, scale);
+        hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(H, B), dim3(256), lds, stream, (const bf16_t*)qkv, (bf16_t*)kcache,
+                           (bf16_t*)vcache, (bf16_t*)out, pos, H, KV, S_max, ld, scale, table);
     CSM_CHECK_LAUNCH("csm_attn_decode");
     return 0;
+}
+
+extern "C" int csm_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* out, const int* pos, int B, int H,
+                               int KV, int HD, int S_max, int ld, hipStream_t stream) {
+    return attn_decode_launch(qkv, const_cast<void*>(kcache), const_cast<void*>(vcache), out, pos, nullptr, B, H, KV, HD, S_max, ld,
+                              stream);
+}
+
+extern "C" int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache, void* out, const int* pos, const float* rope_table,
+                                    int B, int H, int KV, int HD, int S_max, int ld, hipStream_t stream) {
+    CSM_REQUIRE(rope_table, "csm_attn_decode_rope: null table");
+    return attn_decode_launch(qkv, kcache, vcache, out, pos, rope_table, B, H, KV, HD, S_max, ld, stream);
 }

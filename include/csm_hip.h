@@ -131,6 +131,13 @@ int csm_sample_topk(const float* logits, const float* q, int* out, int rows, int
  * y[b][n] = sum_k x[b][k] W[n][k] (+ residual[b][n]), B <= 4 (weight-streaming matrix-vector product) */
 int csm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
                   int out_f32, csm_stream_t stream);
+/* csm_gemv_bf16 with the neighbouring element-wise steps of a decode layer fused in: norm_scale != NULL applies torchtune
+ * RMSNorm (eps) to x first; swiglu = 1 reads W as interleaved gate/up rows (N = 2F) and writes y[b][F] = silu(g) * u;
+ * row_index != NULL takes batch row b of x from row (row_index[b] + row_offset) of the table x (embedding lookup of a
+ * sampled code, model.py:189-191). */
+int csm_gemv_bf16_ex(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
+                     int out_f32, const void* norm_scale, float eps, int swiglu, const int* row_index, int row_offset,
+                     csm_stream_t stream);
 /* y[b][n] = sum_k x[b][k] W[k][n]  (K-major weights: audio_head[i] = [decoder_dim][vocab]) */
 int csm_gemv_t_bf16(const void* x, const void* W, void* y, int B, int N, int K, int ldw, int ldx, int ldy, int out_f32,
                     csm_stream_t stream);
@@ -140,6 +147,11 @@ int csm_kv_append(const void* qkv, void* kcache, void* vcache, const int* pos, i
 /* out[b][h*HD..] = softmax(q . K[0..pos[b]]^T / sqrt(HD)) V   for the single query row in qkv[b] */
 int csm_attn_decode(const void* qkv, const void* kcache, const void* vcache, void* out, const int* pos, int B, int H, int KV,
                     int HD, int S_max, int ld, csm_stream_t stream);
+/* the same with what precedes it in a decode step fused in: q and the new k are rotated inside (table as for csm_rope,
+ * position = pos[b]) and the new k / v are appended to the caches at pos[b] by the kernel itself - one launch instead of
+ * csm_rope + csm_kv_append + csm_attn_decode. qkv is the UNROTATED fused projection row. */
+int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache, void* out, const int* pos, const float* rope_table, int B,
+                         int H, int KV, int HD, int S_max, int ld, csm_stream_t stream);
 
 /* ---- K16 (RVQ part): Mimi split residual VQ behind generator.py:117,209 ------------------------------------------ */
 int csm_rvq_encode(const float* x, const float* codebooks, long long* codes, int T, int K, int C, int D, int n_semantic,

@@ -385,6 +385,46 @@ def test_decode_kernels_vs_oracle(dev):
                 gclose(f"attn_decode b{b} h{h}", out[b, h * hd:(h + 1) * hd], p @ vv[kvh, :n], 1.5e-2)
 
 
+def test_fused_decode_kernels_match_their_parts(dev):
+    """csm_gemv_bf16_ex and csm_attn_decode_rope replace chains of smaller launches in a decode step; they must give the
+    same bits as the chains they replace (and, through those, follow the oracle as tested above)."""
+    from csm.hip import ops
+    from csm.models.model import llama3_rope_table
+    g = torch.Generator().manual_seed(45)
+    for B, K, N in ((1, 1024, 512), (3, 2048, 384)):
+        x = torch.randn(B, K, generator=g).to(BF).to(dev)
+        W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(dev)
+        w = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+        R = torch.randn(B, N, generator=g).to(BF).to(dev)
+        xn, y_ref, y = torch.empty_like(x), torch.empty(B, N, dtype=BF, device=dev), torch.empty(B, N, dtype=BF, device=dev)
+        ops.rmsnorm_fwd(x, w, xn, None, 1e-5)
+        ops.gemv(xn, W, y_ref, residual=R)
+        ops.gemv_ex(x, W, y, residual=R, norm_scale=w, eps=1e-5)
+        assert torch.equal(y, y_ref), "norm + gemv"
+        a_ref, a = torch.empty(B, N // 2, dtype=BF, device=dev), torch.empty(B, N // 2, dtype=BF, device=dev)
+        gu = torch.empty(B, N, dtype=BF, device=dev)
+        ops.gemv(xn, W, gu)
+        ops.swiglu_fwd(gu, a_ref)
+        ops.gemv_ex(x, W, a, norm_scale=w, eps=1e-5, swiglu=True)
+        assert torch.equal(a, a_ref), "norm + gemv + swiglu"
+    for H, KV, hd in ((4, 2, 64), (2, 1, 128)):
+        B, S_max = 2, 96
+        table = llama3_rope_table(S_max, hd, 500000.0, 32.0).to(dev).contiguous()
+        qkv = torch.randn(B, (H + 2 * KV) * hd, generator=g).to(BF).to(dev)
+        kc = torch.randn(B, KV, S_max, hd, generator=g).to(BF)
+        vc = torch.randn(B, KV, S_max, hd, generator=g).to(BF)
+        pos = torch.tensor([70, 0], dtype=torch.int32, device=dev)
+        k1, v1, k2, v2 = kc.to(dev), vc.to(dev), kc.to(dev), vc.to(dev)
+        q1 = qkv.clone()
+        ops.rope(q1, table, 1, H + KV, hd, pos=pos)
+        ops.kv_append(q1, k1, v1, pos, H, KV, hd)
+        o1, o2 = torch.empty(B, H * hd, dtype=BF, device=dev), torch.empty(B, H * hd, dtype=BF, device=dev)
+        ops.attn_decode(q1, k1, v1, o1, pos, H, KV, hd)
+        ops.attn_decode_rope(qkv, k2, v2, o2, pos, table, H, KV, hd)
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), "caches after the fused append"
+        assert torch.equal(o1, o2), "fused rope + append + attention"
+
+
 def test_checkpoint_roundtrip(dev, tmp_path):
     from csm.training.optim import FusedAdamW
     from csm.training.utils import compute_loss, load_checkpoint, save_checkpoint
