@@ -39,7 +39,8 @@ class GradSync:
         self.extra = extra or []
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        # high priority: the collective's few workgroups should get CUs as soon as GEMM workgroups retire, not queue behind them
+        self.comm_stream = torch.cuda.Stream(priority=-1) if self.cuda else None
         self.armed = False
         self.done = set()
         self.handles = []
