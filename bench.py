@@ -152,7 +152,8 @@ def main():
     if world > 1:
         backend = os.environ.get("CSM_BENCH_BACKEND", "nccl")        # nccl == RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            from csm.training.dp import init_nccl
+            init_nccl(rank, world, local)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 

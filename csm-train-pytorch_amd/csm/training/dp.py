@@ -21,8 +21,24 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            init_nccl(rank, world, local)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def init_nccl(rank: int, world: int, local: int):
+    """RCCL process group bound to this rank's GPU, its collectives on a high-priority stream: the all-reduce's few
+    workgroups should get CUs as GEMM workgroups retire instead of queueing behind the whole backward."""
+    kw = dict(rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        dist.init_process_group("nccl", pg_options=opts, **kw)
+    except (AttributeError, TypeError):
+        dist.init_process_group("nccl", **kw)
 
 
 class GradSync:
