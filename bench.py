@@ -28,8 +28,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md, chip-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # SURVEY 8d protocol: >= 10 warm-up, >= 50 timed steps (~5 s of GPU time)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="sequences per GPU")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--mode", choices=["A", "B", "C"], default="C",
@@ -186,6 +186,9 @@ def main():
                              seed=1234 + rank)
     batch = {k: v.cuda() for k, v in collate_variable_length([ds[i] for i in range(a.batch)]).items()}
 
+    K_ = args.audio_num_codebooks
+    cb_tokens = int(batch["input_masks"][:, :, 0].sum()) * K_ + int(batch["input_masks"][:, :, K_].sum())
+
     def step():
         return tr.train_step(batch, 1, True, 1.0)
 
@@ -197,12 +200,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     gt = None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step spread (no host sync inside the loop)
+    marks[0].record()
     for i in range(a.steps):
         if i == a.steps - 1:
             with GemmTimer() as gt:
                 loss, det = step()
         else:
             loss, det = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -216,6 +222,8 @@ def main():
     tokens_per_s = world * a.batch * a.seq / (dt / a.steps)
 
     if rank == 0:
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps - 1)) or [ms]   # last step carries the GEMM timers
+        pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)   # noqa: E731
         kinds = gt.summary() if gt is not None else {}
         bf = {k: v for k, v in kinds.items() if k.endswith("_bf16")}
         dom = max(bf.items(), key=lambda kv: kv[1]["time_ms"]) if bf else (None, None)
@@ -236,7 +244,8 @@ def main():
                        + f" bf16 train step, seq={a.seq}, batch={a.batch}/GPU, loss mode {a.mode}"
                        + (" (semantic CE + depth decoder on 1/16 of frames)" if a.mode == "C" else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq, "parallelism": f"dp{world}"},
-            "loss": float(loss), "roofline": roof,
+            "codebook_tokens_per_s": round(world * cb_tokens / (dt / a.steps), 1),   # secondary: 32 per audio frame + 1 per text token
+            "loss": float(loss), "step_ms": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}, "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
             from oracle import csm_oracle as O
