@@ -106,10 +106,11 @@ class _Stack:
 
     # -------------------------------------------------------------------------------------------- backward
     def backward(self, dxf: torch.Tensor, B: int, S: int, train_base: bool, alpha: float,
-                 pos: Optional[torch.Tensor] = None, on_layer_done=None) -> torch.Tensor:
+                 pos: Optional[torch.Tensor] = None, on_layer_done=None, acc: bool = True) -> torch.Tensor:
         """dxf = gradient w.r.t. the final-norm output.  Returns the gradient w.r.t. the stack input.
-        Weight gradients are accumulated into the gradient arena (scaled by ``alpha``... the incoming gradient is
-        already scaled, so alpha stays 1 unless a caller rescales)."""
+        Weight gradients are added to the gradient arena (``acc``) or overwrite what it holds (``acc=False``: the first
+        backward after a lazy optimizer step, which left consumed gradients behind instead of zeros); the incoming
+        gradient is already scaled, so ``alpha`` stays 1 unless a caller rescales."""
         c, dev = self.c, dxf.device
         M, d = dxf.shape
         H, KV, hd, F = c.num_heads, c.num_kv_heads, c.head_dim, c.intermediate_dim
@@ -122,7 +123,7 @@ class _Stack:
             dx = torch.empty(M, d, dtype=BF16, device=dev)
             ops.rmsnorm_bwd(x, self.w(name), rstd, dy, dx, dres, parts)
             if train_base:
-                ops.colsum_bf16(parts, self.w(name, grad=True), accumulate=True)
+                ops.colsum_bf16(parts, self.w(name, grad=True), accumulate=acc)
             return dx
 
         dx = norm_bwd(self.final["x"], "norm.scale", self.final["rstd"], dxf, None)
@@ -142,7 +143,7 @@ class _Stack:
                 ops.swiglu_bwd(a["gu"], dact, dgu)
                 del dact
             if train_base:
-                ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=True, alpha=alpha)
+                ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=acc, alpha=alpha)
             dhn = torch.empty(M, d, dtype=BF16, device=dev)
             ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
             for mod, col in (("w1", 0), ("w3", 1)):
@@ -150,7 +151,7 @@ class _Stack:
                 if ad is not None:
                     ad.backward(a["hn"], dgu.view(M, F, 2)[:, :, col].contiguous(), a[f"t_{mod}"], dhn)
             if train_base:
-                ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=True, alpha=alpha)
+                ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)
             del dgu
             dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx)   # + residual path
             # ---- attention: h = x + output_proj(o)
@@ -160,7 +161,7 @@ class _Stack:
             if ad is not None:
                 ad.backward(a["o"], dh, a["t_output_proj"], do)
             if train_base:
-                ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=True, alpha=alpha)
+                ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
             dqkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
             ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd)
             ops.rope(dqkv, table, S, H + KV, hd, pos=pos, inverse=True)
@@ -171,7 +172,7 @@ class _Stack:
                 if ad is not None:
                     ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
             if train_base:
-                ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=True, alpha=alpha)
+                ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)
             dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh)
             self.acts[i] = None
             if on_layer_done is not None:
@@ -307,6 +308,25 @@ class Engine:
         tr = m.trainable
         train_embeddings, train_other = tr["embeddings"], tr["other"]
         m.ensure_grads()
+        # Gradient-buffer states (see Model.grad_state): "live" buffers are accumulated into; "stale" ones hold the
+        # gradients a lazy optimizer step consumed and are overwritten by this backward (the weight-gradient GEMMs then
+        # neither read their output nor need a zero fill) - or zeroed here if this backward will not write them.
+        gst = m.grad_state
+        dec_runs = s["dec"] is not None and s["aw"] != 0.0
+        writes = {"backbone": tr["backbone"], "decoder": dec_runs and tr["decoder"], "other": train_other,
+                  "embeddings": train_embeddings}
+        acc = {}
+        for g_, w_ in writes.items():
+            acc[g_] = gst[g_] == "live"
+            if gst[g_] == "stale" and (not w_ or g_ == "embeddings"):
+                o_, n_ = m.group_range(g_)
+                m.grad_arena[o_:o_ + n_].zero_()
+                gst[g_] = "zero"
+            if w_:
+                gst[g_] = "live"
+        if train_other and not acc["other"] and not dec_runs:          # the decoder-side tensors of "other" get no gradient
+            m.block("projection.weight", True).zero_()
+            m.block("audio_head.padded", True).zero_()
         hidden = s["hidden"]
         dseq = None
         dec_pos0 = None
@@ -323,14 +343,15 @@ class Engine:
             xf2 = dec["xf"].view(N, K * dd)
             if train_other:
                 gah = m.block("audio_head.padded", True)
-                ops.gemm(xf2[:, dd:2 * dd], dl[0], gah[0], gah[0], True, True, batch=K - 1, sA=dd, sB=N * Vp,
-                         sC=dd * Vp, sR=dd * Vp)
+                ops.gemm(xf2[:, dd:2 * dd], dl[0], gah[0], gah[0] if acc["other"] else None, True, True, batch=K - 1, sA=dd,
+                         sB=N * Vp, sC=dd * Vp, sR=dd * Vp)
             del dl
-            dx0 = self.decoder.backward(dxf.view(N * K, dd), N, K, tr["decoder"], 1.0, on_layer_done=self.grad_hook)
+            dx0 = self.decoder.backward(dxf.view(N * K, dd), N, K, tr["decoder"], 1.0, on_layer_done=self.grad_hook,
+                                        acc=acc["decoder"])
             dseq = torch.empty(N * K, d, dtype=BF16, device=dev)
             ops.linear_dx(dx0, m.block("projection.weight"), dseq)
             if train_other:
-                ops.linear_dw(dx0, dec["seq"], m.block("projection.weight", True), accumulate=True)
+                ops.linear_dw(dx0, dec["seq"], m.block("projection.weight", True), accumulate=acc["other"])
             dec_pos0 = (dseq, dec["rows"], K)          # position 0 of every frame is the backbone state: scattered below
             if self.grad_hook is not None:
                 self.grad_hook("decoder", -1)
@@ -342,7 +363,7 @@ class Engine:
         dhid = torch.empty(M, d, dtype=BF16, device=dev)
         ops.linear_dx(dlog, m.block("codebook0_head.padded"), dhid)
         if train_other:
-            ops.linear_dw(dlog, hidden, m.block("codebook0_head.padded", True), accumulate=True)
+            ops.linear_dw(dlog, hidden, m.block("codebook0_head.padded", True), accumulate=acc["other"])
         del dlog
         if dec_pos0 is not None:
             ops.rows_add_bf16(dhid, dec_pos0[1], dec_pos0[0], dec_pos0[2])   # rows are unique: plain bf16 read-modify-write
@@ -350,7 +371,7 @@ class Engine:
             self.grad_hook("other", -1)
 
         # ---- backbone
-        dh0 = self.backbone.backward(dhid, B, S, tr["backbone"], 1.0, on_layer_done=self.grad_hook)
+        dh0 = self.backbone.backward(dhid, B, S, tr["backbone"], 1.0, on_layer_done=self.grad_hook, acc=acc["backbone"])
         if train_embeddings:
             self._embedding_backward(s, dh0, dseq if (dec is not None and s["aw"] != 0.0) else None)
         if self.grad_hook is not None:

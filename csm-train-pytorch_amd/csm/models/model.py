@@ -160,6 +160,9 @@ class Model(nn.Module):
         self.lora = None                                      # set by csm.training.lora.apply_lora_to_model
         self.acoustic_mode = "off"                            # "off" (reference placeholder) | "all" | "amortized"
         self.acoustic_fraction = 1.0 / 16.0
+        # state of each group's slice of the gradient arena: "zero" (all zeros), "live" (being accumulated into), "stale"
+        # (consumed by a lazy optimizer step: the next backward overwrites it) - see Engine.backward / FusedAdamW.step
+        self.grad_state = {"backbone": "zero", "decoder": "zero", "embeddings": "zero", "other": "zero"}
         self.target_ignore_index = None                       # e.g. -100: padded target frames leave the loss (data.IGNORE_INDEX)
         self._tables: Dict[str, torch.Tensor] = {}
         self._engine = None

@@ -72,11 +72,23 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = False):
         for g in self.param_groups:
             g["grad"].zero_()
+            if g["name"] in self.model.grad_state:
+                self.model.grad_state[g["name"]] = "zero"
         self._coef = None
+
+    def _settle(self):
+        """A group whose gradients a lazy step consumed and that no backward has rewritten since holds stale values:
+        zero it before it is read again."""
+        gs = self.model.grad_state
+        for g in self.param_groups:
+            if gs.get(g["name"]) == "stale":
+                g["grad"].zero_()
+                gs[g["name"]] = "zero"
 
     def clip_grad_norm(self, max_norm: float) -> torch.Tensor:
         """Global L2 norm over every trainable gradient; the coefficient is consumed by the next ``step``.
         Returns the norm as a 0-d GPU tensor (no host sync)."""
+        self._settle()
         nb = ops.sumsq_blocks()
         for i, g in enumerate(self.param_groups):
             ops.sumsq_bf16(g["grad"], self._partials[i * nb:(i + 1) * nb])
@@ -84,15 +96,26 @@ class FusedAdamW:
         self._coef = self._norm_coef
         return self._norm_coef[0]
 
-    def step(self, zero_grad: bool = False):
-        """One AdamW update.  ``zero_grad=True`` clears the gradients in the same pass over memory (what the trainers
-        use instead of a separate ``zero_grad()``)."""
+    def step(self, zero_grad=False):
+        """One AdamW update.  ``zero_grad=True`` clears the gradients in the same pass over memory.  ``zero_grad="lazy"``
+        (what the trainers use) clears only the embedding tables, whose backward is a scatter-add that needs zeros
+        underneath; the dense groups are marked stale instead and the next backward OVERWRITES them - their weight-gradient
+        GEMMs then skip the read of the old value and nobody writes 2 bytes per parameter of zeros."""
+        self._settle()
         self.step_count += 1
         b1, b2 = self.betas
+        gs = self.model.grad_state
         for g in self.param_groups:
             st = self.state[g["name"]]
+            name = g["name"]
+            zero = bool(zero_grad) if zero_grad != "lazy" else (name == "embeddings" or name not in gs)
             ops.adamw_step(st["master"], st["m"], st["v"], g["param"], g["grad"], g["lr"], b1, b2, self.eps,
-                           g["weight_decay"], self.step_count, self._coef, zero_grad=zero_grad)
+                           g["weight_decay"], self.step_count, self._coef, zero_grad=zero)
+            if name in gs:
+                if zero:
+                    gs[name] = "zero"
+                elif zero_grad == "lazy" and gs[name] == "live":
+                    gs[name] = "stale"
         self._coef = None
 
     def state_dict(self):

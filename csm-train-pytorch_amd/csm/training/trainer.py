@@ -10,6 +10,8 @@ from pathlib import Path
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 
 from ..data import create_dataloader
@@ -96,7 +98,7 @@ class CSMTrainer:
                 self.grad_sync.finish()
             if max_grad_norm and max_grad_norm > 0:
                 self.optimizer.clip_grad_norm(max_grad_norm)
-            self.optimizer.step(zero_grad=True)
+            self.optimizer.step(zero_grad=True if os.environ.get("CSM_EAGER_ZERO_GRAD") else "lazy")
         return loss.detach(), details
 
     def train(self, train_dataset, val_dataset=None, batch_size: int = 2, accumulation_steps: int = 4, epochs: int = 5,

@@ -190,6 +190,33 @@ def test_ignore_index_padding(dev):
     assert abs(float(z) - float(total)) > 1e-3
 
 
+def test_lazy_zero_grad_matches_eager(dev):
+    """``step(zero_grad="lazy")`` (dense gradient groups are overwritten by the next backward instead of being zeroed) must
+    leave exactly the parameters ``zero_grad=True`` leaves - across accumulation windows, a step in which the decoder gets
+    no gradient (its stale buffer has to be cleared), a frozen group and a step without any backward."""
+    from csm.training.optim import FusedAdamW
+    from csm.training.utils import compute_loss
+    results = []
+    for mode in (True, "lazy"):
+        m, _, _ = tiny_model(dev)
+        opt = FusedAdamW(m, {"backbone": 1e-3, "decoder": 2e-3, "embeddings": 5e-4, "other": 1e-3})
+        plan = [("all", 1, {}), ("off", 1, {}), ("all", 2, {}), ("amortized", 1, {"decoder": False}), ("all", 1, {"decoder": True})]
+        for step, (acoustic, n_micro, flags) in enumerate(plan):
+            m.acoustic_mode = acoustic
+            m.trainable.update(flags)
+            for k in range(n_micro):
+                tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=100 + 10 * step + k)
+                rows = torch.arange(0, 2 * 23, 3) if acoustic == "amortized" else None
+                total, _ = compute_loss(m, tokens, mask, targets, acoustic_rows=rows)
+                (total / n_micro).backward()
+            opt.clip_grad_norm(1.0)
+            opt.step(zero_grad=mode)
+        opt.clip_grad_norm(1.0)          # a step with no backward in between: gradients are zero either way
+        opt.step(zero_grad=mode)
+        results.append(m.arena.clone())
+    assert torch.equal(results[0], results[1])
+
+
 def test_lora_step(dev):
     from csm.training.lora import apply_lora_to_model, merge_lora_weights
     from csm.training.utils import compute_loss
