@@ -163,14 +163,11 @@ static bool prefer_256(int M, int N, int K, int batch) {
     return fill * area >= 0.80;
 }
 
-// tuning / A-B switch used by tools/gemm_bench.py: 0 register staging, 1 LDS-DMA 128x128, 2 auto (default), 3 force 256x256
-void csm_gemm256_set_pipelined(int v);
-// 0 register staging, 1 LDS-DMA 128x128, 2 auto (default), 3 force 256x256 (4-quadrant phases), 4 force 256x256 with
-// register-pipelined phases, 5 auto with the 4-quadrant 256 kernel
-// 6 force the persistent-stream 256 kernel, 7 auto with the persistent-stream 256 kernel (measured slower than 2)
+// tuning / A-B switch (tools/gemm_bench.py, tests): 0 = 128x128 kernel with register staging, 1 = 128x128 kernel with
+// LDS-DMA staging, 2 = auto (default: the 256x256 kernel where its tiles fill the chip), 3 = force the 256x256 kernel
 extern "C" int csm_set_gemm_variant(int v) {
-    csm_gemm256_set_pipelined((v == 3 || v == 5) ? 0 : ((v == 6 || v == 7) ? 2 : 1));
-    g_gemm_variant = (v == 4 || v == 6) ? 3 : ((v == 5 || v == 7) ? 2 : v);
+    CSM_REQUIRE(v >= 0 && v <= 3, "csm_set_gemm_variant: %d is not one of 0..3", v);
+    g_gemm_variant = v;
     return 0;
 }
 

@@ -1,18 +1,14 @@
 // 256x256x64 deep-pipelined bf16 MFMA GEMM for gfx950 (same contract and operand layouts as gemm.hip).
 //
 // 512 threads = 8 waves as 2(M) x 4(N); each wave owns a 128x64 output block = 8x4 accumulators of
-// mfma_f32_16x16x32_bf16 (128 VGPRs).  LDS = 128 KiB = 2 K-tile buffers x {A0, A1, B0, B1} half-tiles of 16 KiB
-// (each half-tile is exactly the 128x64 / 64x128 swizzled image of gemm_common.h).  One workgroup per CU.
-//
-// A K-tile is consumed in 4 phases of 16 MFMAs per wave (one 64x32 output quadrant x K=64 each):
-//     ph1 (m0,n0): reads A(m0) 8 + B(n0) 4 fragments      ph2 (m0,n1): reads B(n1) 4
-//     ph3 (m1,n1): reads A(m1) 8                           ph4 (m1,n0): reads nothing
-// and every phase issues ONE half-tile of LDS-DMA (2 x global_load_lds_dwordx4 per wave) for a later K-tile:
-//     ph1(t): A0(t+1) -> buf^1   ph2(t): A1(t+1) -> buf^1   ph3(t): B0(t+2) -> buf   ph4(t): B1(t+2) -> buf
-// The B slots of the current buffer are dead after ph2, the A slots after ph3, which is what makes the re-staging
-// legal one barrier later (WAR); a single counted `s_waitcnt vmcnt(4)` per K-tile in ph4 (everything but the two
-// youngest half-tiles has landed) followed by that phase's barrier covers RAW for the next K-tile.  The loads are
-// never drained to zero inside the loop.  Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
+// mfma_f32_16x16x32_bf16 (128 VGPRs).  One workgroup per CU with all 160 KiB of LDS: A double-buffered, B triple-buffered
+// half-tiles of 16 KiB (each exactly the 128x64 / 64x128 swizzled image of gemm_common.h), filled by LDS-DMA
+// (global_load_lds, 2 instructions per wave and half-tile), never drained to zero inside the loop: ONE counted
+// `s_waitcnt vmcnt(4)` and ONE raw s_barrier per K-tile (a __syncthreads() would drain the DMA queue).  See the kernel
+// comment for the phase schedule.  Two earlier forms - four 64x32 quadrant phases without register prefetch, and a
+// persistent workgroup walking a tile list with the DMA look-ahead running across tile boundaries - measured slower
+// (the persistent one because loads, LDS-DMA and stores share one in-order vmcnt: the next tile's counted waits also wait
+// for the previous tile's stores) and were removed; they are in the history.
 #include "gemm_common.h"
 
 namespace {
@@ -58,113 +54,6 @@ __device__ __forceinline__ void issue_half(const bf16_t* __restrict__ P, int ld,
 
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
-
-template <int TA, int TB, typename OutT>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nwg = g.tiles_m * g.tiles_n;
-    int id = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    }
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * g.tiles_n;
-    const int grp = id / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(g.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (id % per_group) % gsz;
-    const int tn = (id % per_group) / gsz;
-    const int m0 = tm * 256, n0 = tn * 256;
-
-    const int bz = blockIdx.z;
-    const bf16_t* A = g.A + (size_t)bz * g.sA;
-    const bf16_t* B = g.B + (size_t)bz * g.sB;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int a_half = wr;                 // which A half-tile this wave reads
-    const int b_half = wc >> 1;            // which B half-tile
-    const int b_off = (wc & 1) * 64;       // column offset of the wave inside its B half-tile
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nt = g.K / 64;
-    auto slot = [&](int b, int which) { return smem + b * BUF + which * HALF; };
-    auto issueA = [&](int h, int tile, int b) { issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slot(b, h)); };
-    auto issueB = [&](int h, int tile, int b) { issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slot(b, 2 + h)); };
-
-    // ---- prologue: tile 0 complete, B halves of tile 1 in flight
-    issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
-    if (nt > 1) { issueB(0, 1, 1); issueB(1, 1, 1); WAIT_VM(4); } else { WAIT_VM(0); }
-    BARRIER();
-
-    Frags<TA, 4> fa;
-    Frags<TB, 2> fb0, fb1;
-#define MFMA_QUAD(FB, MI, NJ)                                                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-                acc[MI + i][NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB.get(j, ks), fa.get(i, ks), acc[MI + i][NJ + j], 0, 0, 0);
-    for (int t = 0; t < nt; ++t) {
-        const int b = t & 1;
-        const char* la = slot(b, a_half);
-        const char* lb = slot(b, 2 + b_half);
-        // ---------------- phase 1: quadrant (m0, n0)
-        if (t + 1 < nt) issueA(0, t + 1, b ^ 1);
-        fb0.load(lb, b_off, lane);
-        fa.load(la, 0, lane);
-        frag_wait();
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(fb0, 0, 0)
-        __builtin_amdgcn_s_setprio(0);
-        BARRIER();
-        // ---------------- phase 2: quadrant (m0, n1)
-        if (t + 1 < nt) issueA(1, t + 1, b ^ 1);
-        fb1.load(lb, b_off + 32, lane);
-        frag_wait();
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(fb1, 0, 2)
-        __builtin_amdgcn_s_setprio(0);
-        BARRIER();
-        // ---------------- phase 3: quadrant (m1, n1)
-        if (t + 2 < nt) issueB(0, t + 2, b);
-        fa.load(la, 64, lane);
-        frag_wait();
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(fb1, 4, 2)
-        __builtin_amdgcn_s_setprio(0);
-        BARRIER();
-        // ---------------- phase 4: quadrant (m1, n0)
-        if (t + 2 < nt) issueB(1, t + 2, b);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(fb0, 4, 0)
-        __builtin_amdgcn_s_setprio(0);
-        if (t + 2 < nt) { WAIT_VM(4); } else { WAIT_VM(0); }   // tile t+1 has landed; at most B0/B1(t+2) in flight
-        BARRIER();
-    }
-#undef MFMA_QUAD
-
-    // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] of each 16x16 tile
-    Epi e;
-    e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
-    e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
-    e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
-    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
-    const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + 16 * i + (lane & 15);
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp)
-            epi_store_pair<OutT>(e, vec_ok, m, n0 + wc * 64 + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Variant with register-level software pipelining: a phase multiplies ONE pair of A m-tiles (32 rows) by all four B
@@ -215,6 +104,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Issue order of the A half-tiles: measured per operand layout (tools/probes/ablate_gemm.sh "0 16", 9-round medians):
+    // both halves of tile t+2 in ph4(t) gives the younger half one more phase of latency slack and is 4-6 % faster
+    // for nn (dgrad) shapes, neutral for nt, 2 % slower for tn - so it is the default for nn only.
+    constexpr bool EARLY = EARLY_A1 || (TA == 0 && TB == 1);
     const int nt = g.K / 64;
     // LDS map (160 KiB): A double-buffered [2][2 halves] at 0..64 KiB, B TRIPLE-buffered [3][2 halves] at 64..160 KiB
     auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
@@ -226,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
     if (nt > 1) {
         issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1);
-        if (EARLY_A1) { issueA(1, 1, 1); WAIT_VM(8); } else { WAIT_VM(6); }
+        if (EARLY) { issueA(1, 1, 1); WAIT_VM(8); } else { WAIT_VM(6); }
     } else { WAIT_VM(0); }
     BARRIER();
 
@@ -250,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
         const char* la = slotA(b, a_half);
         const char* lb = slotB(b3, b_half);
         // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
-        if (!EARLY_A1 && t + 1 < nt) issueA(1, t + 1, b ^ 1);
+        if (!EARLY && t + 1 < nt) issueA(1, t + 1, b ^ 1);
         if (EARLY_B && t + 2 < nt) issueB(0, t + 2, b3n);
         if (!ABL_L) { fb.load(lb, b_off, lane);
         fa1.load(la, 32, lane); }
@@ -271,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
         if (t + 2 < nt) { WAIT_VM(4); } else { WAIT_VM(0); }    // tile t+1 has landed
         if (!ABL_B) BARRIER();
         // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
-        if (t + 2 < nt) { issueA(0, t + 2, b); if (EARLY_A1) issueA(1, t + 2, b); }
+        if (t + 2 < nt) { issueA(0, t + 2, b); if (EARLY) issueA(1, t + 2, b); }
         if (!ABL_L && t + 1 < nt) fa0.load(slotA(b ^ 1, a_half), 0, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 6)
@@ -302,194 +195,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent "continuous stream" form of the pipelined kernel: min(#tiles, #CUs) workgroups, each walking its list of
-// output tiles as ONE uninterrupted sequence of K-steps.  The LDS-DMA look-ahead runs across tile boundaries (the
-// half-tiles of the next tile's first two K-steps are issued during the current tile's last two), so a new tile starts
-// with its operands already in LDS and the only per-tile bubble left is the epilogue store burst itself.
-// vmcnt bookkeeping: loads, LDS-DMA and stores share one in-order counter.  The A1 half-tile that the next step's ph1
-// would issue is issued BEFORE the epilogue stores; the first counted wait after a full-tile epilogue (exactly 16 16-byte store
-// instructions per wave) is vmcnt(20) = 16 stores + the two B half-tiles, any other case falls back to vmcnt(4), which
-// merely also waits for the stores.
-struct TileDesc {
-    const bf16_t* A; const bf16_t* B; int m0, n0, bz; bool valid;
-};
-
-template <int TA, int TB, typename OutT>
-__global__ __launch_bounds__(512, 2) void gemm256s_kernel(Gemm256Args g, int total, int batch_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int a_half = wr, b_half = wc >> 1, b_off = (wc & 1) * 64;
-    const int P = gridDim.x;
-    const int nt = g.K / 64;   // >= 2 (host guarantees)
-
-    auto make = [&](int L) {
-        TileDesc d;
-        d.valid = L < total;
-        d.A = g.A; d.B = g.B; d.m0 = 0; d.n0 = 0; d.bz = 0;
-        if (d.valid) {
-            const int q = total >> 3, r = total & 7, xcd = L & 7, within = L >> 3;
-            const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-            const int bz = nid / batch_tiles;
-            const int id = nid - bz * batch_tiles;
-            constexpr int GROUP_M = 4;
-            const int per_group = GROUP_M * g.tiles_n;
-            const int grp = id / per_group;
-            const int first_m = grp * GROUP_M;
-            const int gsz = min(g.tiles_m - first_m, GROUP_M);
-            const int tm = first_m + (id % per_group) % gsz;
-            const int tn = (id % per_group) / gsz;
-            d.m0 = tm * 256; d.n0 = tn * 256; d.bz = bz;
-            d.A = g.A + (size_t)bz * g.sA;
-            d.B = g.B + (size_t)bz * g.sB;
-        }
-        return d;
-    };
-    auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
-    auto slotB = [&](int b3, int h) { return smem + 4 * HALF + b3 * (2 * HALF) + h * HALF; };
-    auto issueA = [&](const TileDesc& d, int h, int kt, int b) { issue_half<TA>(d.A, g.lda, g.M, d.m0 + h * 128, kt * 64, slotA(b, h)); };
-    auto issueB = [&](const TileDesc& d, int h, int kt, int b3) { issue_half<TB>(d.B, g.ldb, g.N, d.n0 + h * 128, kt * 64, slotB(b3, h)); };
-    constexpr int NRA = (TA == 0) ? 4 : 8;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int L = blockIdx.x;
-    TileDesc cur = make(L), nxt = make(L + P);
-    // prologue: K-step 0 complete, K-step 1 minus its A1 half in flight
-    issueA(cur, 0, 0, 0); issueA(cur, 1, 0, 0); issueB(cur, 0, 0, 0); issueB(cur, 1, 0, 0);
-    issueB(cur, 0, 1, 1); issueB(cur, 1, 1, 1); issueA(cur, 0, 1, 1);
-    WAIT_VM(6);
-    BARRIER();
-
-    Frags<TB, 4> fb;
-    Frags<TA, 2> fa0, fa1;
-    fa0.load(slotA(0, a_half), 0, lane);
-    int sb = 0, s3 = 0;               // global K-step parity and (step % 3)
-    bool a1_preissued = false, stores_pending = false;
-#define MFMA_PAIR(FA, MI)                                                                                              \
-    __builtin_amdgcn_s_setprio(1);                                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
-                acc[MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), FA.get(i, ks), acc[MI + i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-
-    while (cur.valid) {
-        for (int t = 0; t < nt; ++t) {
-            const bool has1 = (t + 1 < nt) || nxt.valid;
-            const bool has2 = (t + 2 < nt) || nxt.valid;
-            const TileDesc& d1 = (t + 1 < nt) ? cur : nxt;
-            const TileDesc& d2 = (t + 2 < nt) ? cur : nxt;
-            const int k1 = (t + 1 < nt) ? t + 1 : t + 1 - nt;
-            const int k2 = (t + 2 < nt) ? t + 2 : t + 2 - nt;
-            const int s3n = s3 == 0 ? 2 : s3 - 1;       // (step + 2) % 3
-            const char* la = slotA(sb, a_half);
-            // ---- ph1
-            if (has1 && !a1_preissued) issueA(d1, 1, k1, sb ^ 1);
-            a1_preissued = false;
-            fb.load(slotB(s3, b_half), b_off, lane);
-            fa1.load(la, 32, lane);
-            WAIT_LGKM(NRA);
-            MFMA_PAIR(fa0, 0)
-            // ---- ph2
-            if (has2) issueB(d2, 0, k2, s3n);
-            fa0.load(la, 64, lane);
-            WAIT_LGKM(NRA);
-            MFMA_PAIR(fa1, 2)
-            // ---- ph3
-            if (has2) issueB(d2, 1, k2, s3n);
-            fa1.load(la, 96, lane);
-            WAIT_LGKM(NRA);
-            MFMA_PAIR(fa0, 4)
-            WAIT_LGKM(0);
-            if (has2) { if (stores_pending) { WAIT_VM(20); } else { WAIT_VM(4); } } else { WAIT_VM(0); }
-            stores_pending = false;
-            BARRIER();
-            // ---- ph4
-            if (has2) issueA(d2, 0, k2, sb);
-            if (has1) fa0.load(slotA(sb ^ 1, a_half), 0, lane);
-            WAIT_LGKM(NRA);
-            MFMA_PAIR(fa1, 6)
-            sb ^= 1;
-            s3 = s3 == 2 ? 0 : s3 + 1;
-        }
-        // ---- tile boundary: the next step's ph1 issue goes out before the store burst
-        if (nxt.valid) { issueA(nxt, 1, 1, sb ^ 1); a1_preissued = true; }
-        Epi e;
-        e.C = reinterpret_cast<OutT*>(g.C) + (size_t)cur.bz * g.sC;
-        e.R = g.R ? g.R + (size_t)cur.bz * g.sR : nullptr;
-        e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
-        e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
-        const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
-        const bool interior = vec_ok && cur.m0 + 256 <= g.M && cur.n0 + 256 <= g.N && g.epi_mode == EPI_NONE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = cur.m0 + wr * 128 + 16 * i + (lane & 15);
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                epi_store_pair<OutT>(e, vec_ok, m, cur.n0 + wc * 64 + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
-                acc[i][2 * jp] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[i][2 * jp + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        stores_pending = interior && !e.R && sizeof(OutT) == 2 && (g.ldc & 7) == 0;   // exactly 16 wide stores, no loads, by this wave
-        cur = nxt;
-        L += P;
-        nxt = make(L + P);
-    }
-#undef MFMA_PAIR
-}
-
-int g_gemm256_pipelined = 1;   // 0: 4-quadrant phases, 1: register-pipelined, 2: persistent continuous stream
-
-
 template <int TA, int TB>
 int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) {
     dim3 grid(g.tiles_m * g.tiles_n, 1, batch), block(512);
-    const size_t lds = 2 * BUF;
-    static bool attr_done[2] = {false, false};
-    if (g_gemm256_pipelined == 2 && g.K >= 128) {
-        const size_t lds = 10 * HALF;
-        const int batch_tiles = g.tiles_m * g.tiles_n;
-        const int total = batch_tiles * batch;
-        static int n_cu = 0;
-        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, dev); n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
-        dim3 pgrid(total < n_cu ? total : n_cu);
-        static bool sdone[2] = {false, false};
-        if (out_f32) {
-            auto k = gemm256s_kernel<TA, TB, float>;
-            if (!sdone[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); sdone[1] = true; }
-            hipLaunchKernelGGL(k, pgrid, block, lds, stream, g, total, batch_tiles);
-        } else {
-            auto k = gemm256s_kernel<TA, TB, bf16_t>;
-            if (!sdone[0]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); sdone[0] = true; }
-            hipLaunchKernelGGL(k, pgrid, block, lds, stream, g, total, batch_tiles);
-        }
-    } else if (g_gemm256_pipelined) {
-        const size_t lds = 10 * HALF;   // 160 KiB
-        static bool pdone[2] = {false, false};
-        if (out_f32) {
-            auto k = gemm256p_kernel<TA, TB, float>;
-            if (!pdone[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); pdone[1] = true; }
-            hipLaunchKernelGGL(k, grid, block, lds, stream, g);
-        } else {
-            auto k = gemm256p_kernel<TA, TB, bf16_t>;
-            if (!pdone[0]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); pdone[0] = true; }
-            hipLaunchKernelGGL(k, grid, block, lds, stream, g);
-        }
-    } else if (out_f32) {
-        auto k = gemm256_kernel<TA, TB, float>;
-        if (!attr_done[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    const size_t lds = 10 * HALF;   // 160 KiB: the whole LDS of a CU
+    static bool done[2] = {false, false};
+    if (out_f32) {
+        auto k = gemm256p_kernel<TA, TB, float>;
+        if (!done[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[1] = true; }
         hipLaunchKernelGGL(k, grid, block, lds, stream, g);
     } else {
-        auto k = gemm256_kernel<TA, TB, bf16_t>;
-        if (!attr_done[0]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+        auto k = gemm256p_kernel<TA, TB, bf16_t>;
+        if (!done[0]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[0] = true; }
         hipLaunchKernelGGL(k, grid, block, lds, stream, g);
     }
     CSM_CHECK_LAUNCH("csm_gemm_bf16(256)");
@@ -497,8 +214,6 @@ int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) 
 }
 
 }  // namespace
-
-void csm_gemm256_set_pipelined(int v) { g_gemm256_pipelined = v; }
 
 // called by csm_gemm_bf16 (gemm.hip) when the tile heuristic picks the 256x256 kernel; same argument meaning
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,

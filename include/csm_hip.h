@@ -50,9 +50,8 @@ int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M
                      long long strideB, long long strideC, long long strideR, int epilogue, const void* aux_in,
                      void* aux_out, int ld_aux, csm_stream_t stream);
 
-/* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = 256x256 pipelined kernel
- * where its tiles fill the chip, else 128x128 (default); 3/4/6 force the 256x256 kernel (4-quadrant / pipelined /
- * persistent-stream form); 5/7 auto with the 4-quadrant / persistent form */
+/* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = the 256x256 pipelined kernel
+ * where its tiles fill the chip, else 128x128 (default); 3 force the 256x256 kernel */
 int csm_set_gemm_variant(int v);
 
 /* ---- K2: torchtune RMSNorm (sa_norm / mlp_norm / norm; eps=1e-5 at model.py:22,39) -------------------------- */

@@ -20,7 +20,7 @@ for name, M, N, K in (("o_proj dW", 8192, 2048, 2048), ("qkv dW", 8192, 3072, 20
     res = []
     res.append(("heuristic", t(lambda: ops.linear_dw(dy, x, out, accumulate=True))))
     res.append(("direct", t(lambda: ops.gemm(dy, x, out, out, True, True))))
-    for v in (1, 3):
+    for v in (1, 3):  # 128x128 LDS-DMA kernel, forced 256x256 kernel
         ops.lib.csm_set_gemm_variant(v)
         res.append((f"direct v{v}", t(lambda: ops.gemm(dy, x, out, out, True, True))))
     ops.lib.csm_set_gemm_variant(2)
