@@ -56,21 +56,23 @@ __device__ __forceinline__ void issue_half(const bf16_t* __restrict__ P, int ld,
 #define BARRIER() __builtin_amdgcn_s_barrier()
 
 // ---------------------------------------------------------------------------------------------------------------
-// Variant with register-level software pipelining: a phase multiplies ONE pair of A m-tiles (32 rows) by all four B
-// n-tiles of the wave (16 MFMAs) while the NEXT pair's fragments are already being read from LDS into the other A
-// register set, so fragment reads run under the MFMAs instead of in front of them.  Only the 8 B fragment reads at
-// the start of a K-tile are exposed.  Slot liveness: B slots of the current buffer are dead after ph1, A slots after
-// ph3 (ph3 drains its prefetch reads before the barrier), giving the DMA order
-//     ph1(t): A1(t+1) -> buf^1    ph2(t): B0(t+2) -> buf    ph3(t): B1(t+2) -> buf    ph4(t): A0(t+2) -> buf
-// and one counted wait per K-tile at the end of ph3 (vmcnt(4): everything up to A1(t+1) has landed).
+// A K-tile is four phases.  A phase multiplies ONE pair of A m-tiles (32 rows) by all four B n-tiles of the wave
+// (16 MFMAs) while the NEXT pair's fragments are already being read from LDS into the other A register set, so fragment
+// reads run under the MFMAs instead of in front of them.  Only the 8 B fragment reads at the start of a K-tile are
+// exposed.  Slot liveness: the B slot of tile t is dead after ph1(t)'s reads, the A slots after ph3(t) (which drains its
+// prefetch reads before the barrier); the single barrier at the end of ph3 releases both and publishes tile t+1.  The
+// LDS-DMA of later tiles is spread over the phases (order per operand layout: see EARLY / EARLYB in the kernel), e.g.
+//     ph1(t): B0(t+2)    ph2(t): B1(t+2)    ph3(t): -    [wait, barrier]    ph4(t): A0(t+2), A1(t+2)
+// with one counted wait per K-tile at the end of ph3 (vmcnt(4): all but the two youngest B half-tiles have landed).
 // Experiment switches for tools/probes/ablate_gemm.sh (never set in the shipped build): drop one ingredient of the main
 // loop to see what bounds it.  bit0: no LDS-DMA after the prologue; bit1: no fragment reads; bit2: no MFMA; bit3: no barrier.
 #ifndef CSM_ABLATE
 #define CSM_ABLATE 0
 #endif
 constexpr bool ABL_G = CSM_ABLATE & 1, ABL_L = CSM_ABLATE & 2, ABL_M = CSM_ABLATE & 4, ABL_B = CSM_ABLATE & 8;
-constexpr bool EARLY_B = CSM_ABLATE & 32;    // with EARLY_A1: B halves of tile t+2 in ph1/ph2 instead of ph2/ph3
-constexpr bool EARLY_A1 = CSM_ABLATE & 16;   // issue both A halves of tile t+2 in ph4(t) (one more phase of latency slack for A1)
+constexpr bool NO_PRIO = CSM_ABLATE & 64;    // no s_setprio around the MFMA groups
+constexpr bool EARLY_B = CSM_ABLATE & 32;    // flip the layout's default for the B half-tile issue phases (see the kernel)
+constexpr bool EARLY_A1 = CSM_ABLATE & 16;   // flip: A1 of the next tile in ph1 instead of with A0 in ph4
 
 template <int TA, int TB, typename OutT>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
@@ -104,10 +106,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Issue order of the A half-tiles: measured per operand layout (tools/probes/ablate_gemm.sh "0 16", 9-round medians):
-    // both halves of tile t+2 in ph4(t) gives the younger half one more phase of latency slack and is 4-6 % faster
-    // for nn (dgrad) shapes, neutral for nt, 2 % slower for tn - so it is the default for nn only.
-    constexpr bool EARLY = EARLY_A1 || (TA == 0 && TB == 1);
+    // Issue order of the LDS-DMA half-tiles, measured per operand layout (tools/probes/ablate_gemm.sh, 5..9-round medians
+    // on the train-step shapes; bits 16 / 32 of CSM_ABLATE flip the two choices):
+    //   EARLY  - both A halves of tile t+2 in ph4(t) instead of A0 in ph4(t), A1 in ph1(t+1): the younger half gets one
+    //            more phase of latency slack.  nn: 4-6 % faster; with EARLYB also nt (2-5 %) and tn (7 %).
+    //   EARLYB - the B halves of tile t+2 in ph1/ph2 instead of ph2/ph3.  Helps nt and tn, costs nn 5 % -> off for nn.
+    // Putting all four in one phase (ph4: A(t+2), B(t+3)) was 4-12 % slower: the DMA wants to be spread out.
+    constexpr bool NN = (TA == 0 && TB == 1);
+    constexpr bool EARLY = !EARLY_A1;
+    constexpr bool EARLYB = EARLY_B ? NN : !NN;
     const int nt = g.K / 64;
     // LDS map (160 KiB): A double-buffered [2][2 halves] at 0..64 KiB, B TRIPLE-buffered [3][2 halves] at 64..160 KiB
     auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
@@ -130,12 +137,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     int b3 = 0;   // t % 3
 #define WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MFMA_PAIR(FA, MI)                                                                                              \
-    if (!ABL_M) { __builtin_amdgcn_s_setprio(1);                                                                                     \
+    if (!ABL_M) { if (!NO_PRIO) __builtin_amdgcn_s_setprio(1);                                                                                     \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
                 acc[MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), FA.get(i, ks), acc[MI + i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0); }
+    if (!NO_PRIO) __builtin_amdgcn_s_setprio(0); }
 
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
@@ -144,19 +151,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
         const char* lb = slotB(b3, b_half);
         // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
         if (!EARLY && t + 1 < nt) issueA(1, t + 1, b ^ 1);
-        if (EARLY_B && t + 2 < nt) issueB(0, t + 2, b3n);
+        if (EARLYB && t + 2 < nt) issueB(0, t + 2, b3n);
         if (!ABL_L) { fb.load(lb, b_off, lane);
         fa1.load(la, 32, lane); }
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 0)
         // ---- ph2: pair 1 (set 1)   | prefetch pair 2 -> set 0
-        if (t + 2 < nt) issueB(EARLY_B ? 1 : 0, t + 2, b3n);
+        if (t + 2 < nt) issueB(EARLYB ? 1 : 0, t + 2, b3n);
         if (!ABL_L) fa0.load(la, 64, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 2)
         // (no barrier: the B slots were released by ph1's barrier, nothing new has to be visible yet)
         // ---- ph3: pair 2 (set 0)   | prefetch pair 3 -> set 1
-        if (!EARLY_B && t + 2 < nt) issueB(1, t + 2, b3n);
+        if (!EARLYB && t + 2 < nt) issueB(1, t + 2, b3n);
         if (!ABL_L) fa1.load(la, 96, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 4)
