@@ -6,6 +6,11 @@ ring-collective payload per launch, so buckets are arena slices (no flatten / co
 
 The sum (not mean) is reduced; callers pre-scale the loss gradient by 1 / world_size so the result is the mean.
 Device-agnostic on purpose: with the ``gloo`` backend and CPU tensors the same bucket logic is unit-tested.
+
+The text-embedding gradient is the exception to "all-reduce the slice": it is the largest tensor (128256 x 2048 = 525 MB
+in bf16), it is final only when the whole backward is (nothing left to hide its all-reduce behind), and a step touches a
+few hundred of its rows.  On the GPU the ranks therefore exchange (row id, gradient row) lists with an all-gather of a few
+MB and add them in rank order - every rank ends up with bit-identical gradients, as after an all-reduce.
 """
 import os
 from typing import Callable, Dict, List, Optional, Tuple
@@ -61,6 +66,7 @@ class GradSync:
         self.done = set()
         self.handles = []
         self.launch_log: List[tuple] = []
+        self.sparse: Optional[dict] = None        # text-embedding rows exchanged as lists (set by for_model on the GPU)
 
     @staticmethod
     def active() -> bool:
@@ -86,9 +92,15 @@ class GradSync:
             else:
                 key = ("other", -1)
             buckets.setdefault(key, []).append((s.offset, s.numel))
+        sparse = None
+        if ("embeddings", -1) in buckets and model.grad_arena.is_cuda and os.environ.get("CSM_DP_DENSE_EMBEDDINGS") != "1":
+            t = slots["text_embeddings.weight"]
+            buckets[("embeddings", -1)] = [sl for sl in buckets[("embeddings", -1)] if sl != (t.offset, t.numel)]
+            sparse = dict(slice=(t.offset, t.numel), D=model.bb.embed_dim, seen=[], rows=None, counts=None)
         merged = {k: cls._merge(v) for k, v in buckets.items()}
         extra = [model.lora.grad_arena] if model.lora is not None else []
         gs = cls(model.grad_arena, merged, group, extra)
+        gs.sparse = sparse
         model.engine.grad_hook = gs.on_ready
         return gs
 
@@ -103,14 +115,66 @@ class GradSync:
                 out.append((off, n))
         return out
 
+    SPARSE_MAX_ROWS = 16384       # beyond this many touched text rows per rank the dense all-reduce is used instead
+
+    def note_batch(self, tokens: torch.Tensor, masks: torch.Tensor):
+        """Remember which text-embedding rows this micro-batch touches (column K of the live text slots)."""
+        if self.sparse is None:
+            return
+        k = tokens.shape[-1] - 1
+        t, mk = tokens[..., k].reshape(-1), masks[..., k].reshape(-1).bool()
+        self.sparse["seen"].append(t[mk].to(self.flat.device, torch.int64))
+
     def arm(self, enabled: bool = True):
         """Call before a backward: ``enabled`` only on the micro-batch that ends an accumulation window."""
         self.armed = enabled and self.world_size > 1
         self.done = set()
         self.handles = []
+        if self.armed and self.sparse is not None:
+            # union of the window's text rows and every rank's count, exchanged now - before the backward - so that the
+            # one host sync this needs does not sit at the end of the step behind all the queued collectives
+            sp = self.sparse
+            rows = torch.unique(torch.cat(sp["seen"])) if sp["seen"] else torch.empty(0, dtype=torch.int64, device=self.flat.device)
+            sp["seen"] = []
+            cnt = torch.tensor([rows.numel()], dtype=torch.int64, device=self.flat.device)
+            got = [torch.zeros_like(cnt) for _ in range(self.world_size)]
+            dist.all_gather(got, cnt, group=self.group)
+            sp["rows"], sp["counts"] = rows.to(torch.int32), [int(x) for x in got]
+
+    def _launch_text_rows(self):
+        """All-gather (row id, gradient row) of the text-embedding rows each rank touched and add them in rank order."""
+        sp = self.sparse
+        o, n = sp["slice"]
+        counts, D = sp["counts"], sp["D"]
+        if max(counts) > self.SPARSE_MAX_ROWS:
+            self._launch([self.flat[o:o + n]], ("embeddings", "text-dense"))
+            return
+        from ..hip import ops
+        self.launch_log.append(("embeddings", "text-rows"))
+        cap = max(64, (max(counts) + 63) // 64 * 64)
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            g = self.flat[o:o + n].view(-1, D)
+            rows, mine = sp["rows"], sp["rows"].numel()
+            send_r = torch.full((cap,), -1, dtype=torch.int32, device=g.device)
+            send_g = torch.zeros(cap, D, dtype=g.dtype, device=g.device)
+            if mine:
+                send_r[:mine] = rows
+                send_g[:mine] = g[rows.long()]
+            all_r = [torch.empty_like(send_r) for _ in range(self.world_size)]
+            all_g = [torch.empty_like(send_g) for _ in range(self.world_size)]
+            dist.all_gather(all_r, send_r, group=self.group)
+            dist.all_gather(all_g, send_g, group=self.group)
+            if mine:
+                g.index_fill_(0, rows.long(), 0)
+            for r in range(self.world_size):                      # fixed order: every rank computes the same bits
+                if counts[r]:
+                    ops.rows_add_bf16(g, all_r[r][:counts[r]].contiguous(), all_g[r], 1)
 
     def _launch(self, tensors: List[torch.Tensor], key):
         self.launch_log.append(key)
+        if not tensors:
+            return
         if self.cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -127,6 +191,8 @@ class GradSync:
         if key in self.buckets and key not in self.done:
             self.done.add(key)
             self._launch([self.flat[o:o + n] for o, n in self.buckets[key]], key)
+            if key == ("embeddings", -1) and self.sparse is not None:
+                self._launch_text_rows()
 
     def finish(self):
         """Reduce anything not yet announced, then make the compute stream wait for the communication stream."""
@@ -136,6 +202,8 @@ class GradSync:
             if key not in self.done:
                 self.done.add(key)
                 self._launch([self.flat[o:o + n] for o, n in self.buckets[key]], key)
+                if key == ("embeddings", -1) and self.sparse is not None:
+                    self._launch_text_rows()
         if self.extra:
             self._launch(list(self.extra), ("extra", -1))
         if self.cuda:

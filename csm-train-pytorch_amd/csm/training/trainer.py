@@ -86,6 +86,7 @@ class CSMTrainer:
         """One micro-batch: loss -> backward (-> on the boundary micro-batch: all-reduce, clip, AdamW, zero_grad)."""
         m = self.model
         if self.grad_sync is not None:
+            self.grad_sync.note_batch(batch["input_tokens"], batch["input_masks"])
             self.grad_sync.arm(is_boundary)
         loss, details = compute_loss(m, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"],
                                      self.semantic_weight, self.acoustic_weight)

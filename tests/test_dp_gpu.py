@@ -106,6 +106,7 @@ def test_two_rank_dp_matches_single_process(dev, mode):
         first = log0[:len(log0) // 2]
         assert first.index(("decoder", 1)) < first.index(("decoder", 0)) < first.index(("other", -1)) < first.index(("backbone", 1)) \
             < first.index(("backbone", 0)) < first.index(("embeddings", -1))
+        assert first[-1] == ("embeddings", "text-rows"), "text-embedding rows go through the row-list exchange, last"
     ref = _single(mode)
     err = (s0 - ref).abs().max().item()
     # Adam moves a weight by ~lr per step whatever the gradient's size, so an element whose (tiny) gradient changes
