@@ -25,6 +25,7 @@ F32 = torch.float32
 # exposed; the gain is what remains after that).  CSM_FUSE_SWIGLU=0 restores the stand-alone path for re-evaluation.
 import os as _os
 FUSE_SWIGLU = _os.environ.get("CSM_FUSE_SWIGLU", "1") == "1"
+FUSE_ROPE_BWD = _os.environ.get("CSM_FUSE_ROPE_BWD", "1") == "1"      # A/B switch: RoPE backward inside the attention backward
 
 
 class _Stack:
@@ -163,8 +164,11 @@ class _Stack:
             if train_base:
                 ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
             dqkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
-            ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd)
-            ops.rope(dqkv, table, S, H + KV, hd, pos=pos, inverse=True)
+            if pos is None and FUSE_ROPE_BWD:     # positions = arange(S): the RoPE backward rides in the dQ / dK epilogues
+                ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd, rope_table=table)
+            else:
+                ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd)
+                ops.rope(dqkv, table, S, H + KV, hd, pos=pos, inverse=True)
             dxn = torch.empty(M, d, dtype=BF16, device=dev)
             ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
             for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):

@@ -42,6 +42,7 @@ _SIGS = {
     "csm_set_attn_variant": ([_i], _i),
     "csm_attn_fwd": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "csm_attn_bwd_rope": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_swiglu_fwd": ([_p, _p, _ll, _i, _p], _i),
     "csm_swiglu_bwd": ([_p, _p, _p, _ll, _i, _p], _i),
     "csm_embed_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),

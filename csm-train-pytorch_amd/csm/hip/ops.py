@@ -162,10 +162,17 @@ def attn_fwd(qkv, out, lse, B, S, H, KV, HD):
     return out
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, S, H, KV, HD):
+def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, S, H, KV, HD, rope_table=None):
+    """dqkv = gradient of the (rotated) q | k | v rows; with ``rope_table`` the RoPE backward is applied in the dQ / dK
+    epilogues and dqkv is the gradient of the un-rotated projection output (positions = row index in the sequence)."""
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
-    check(lib.csm_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                           delta_ws.data_ptr(), B, S, H, KV, HD, _stream()), "csm_attn_bwd")
+    if rope_table is None:
+        check(lib.csm_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                               delta_ws.data_ptr(), B, S, H, KV, HD, _stream()), "csm_attn_bwd")
+    else:
+        assert rope_table.dtype == torch.float32 and rope_table.is_contiguous() and rope_table.shape[0] >= S
+        check(lib.csm_attn_bwd_rope(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                    delta_ws.data_ptr(), rope_table.data_ptr(), B, S, H, KV, HD, _stream()), "csm_attn_bwd_rope")
     return dqkv
 
 

@@ -120,6 +120,17 @@ __device__ __forceinline__ float rows_sum(float x) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Backward of torchtune's interleaved-pair RoPE on two adjacent pairs (x0,x1), (x2,x3) of position p: the transpose
+// rotation, (g0 c + g1 s, g1 c - g0 s).  table = [P][hd/2][2] (cos, sin) fp32 as for csm_rope; pair = first pair index.
+// Fusing it into the dQ / dK epilogues saves the separate in-place pass over the [M, (H+2KV) hd] gradient.
+__device__ __forceinline__ void unrope2(const float* __restrict__ table, int p, int hd, int pair, float& g0, float& g1, float& g2,
+                                        float& g3) {
+    const float4 t = *reinterpret_cast<const float4*>(table + ((size_t)p * (hd >> 1) + pair) * 2);   // c0, s0, c1, s1
+    const float a0 = g0 * t.x + g1 * t.y, a1 = g1 * t.x - g0 * t.y;
+    const float a2 = g2 * t.z + g3 * t.w, a3 = g3 * t.z - g2 * t.w;
+    g0 = a0; g1 = a1; g2 = a2; g3 = a3;
+}
+
 // experiment switches for tools/probes (never set in the shipped build): what bounds the dK/dV loop?
 // bit0: no global prefetch / LDS commit after the first tile; bit1: no softmax VALU work; bit2: no LDS fragment reads
 #ifndef CSM_ATT_ABLATE
@@ -135,7 +146,7 @@ template <int HD, bool BWD, int QT>
 __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, const bf16_t* __restrict__ dout,
                                                      float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                     int S, int H, int KV, float scale, int lpt) {
+                                                     int S, int H, int KV, float scale, int lpt, const float* __restrict__ rope) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32;
     constexpr int NIMG = 2;
     using I = Img<HD>;
@@ -347,7 +358,9 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
             bf16_t* op = dqkv + ((size_t)b * S + qrow[qt]) * ld + h * HD;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                uint2 w; w.x = pack2bf(o[qt][dt][0] * scale, o[qt][dt][1] * scale); w.y = pack2bf(o[qt][dt][2] * scale, o[qt][dt][3] * scale);
+                float v0 = o[qt][dt][0] * scale, v1 = o[qt][dt][1] * scale, v2 = o[qt][dt][2] * scale, v3 = o[qt][dt][3] * scale;
+                if (rope) unrope2(rope, qrow[qt], HD, 8 * dt + 2 * g, v0, v1, v2, v3);   // gradient w.r.t. the un-rotated q
+                uint2 w; w.x = pack2bf(v0, v1); w.y = pack2bf(v2, v3);
                 *reinterpret_cast<uint2*>(op + 16 * dt + 4 * g) = w;
             }
         }
@@ -361,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
 template <int HD, int KT>
 __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale, int map) {
+                                                          bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale, int map,
+                                                          const float* __restrict__ rope) {
     constexpr int NKS = HD / 32, NDT = HD / 16, NST = HD / 32, KB = 64 * KT;
     using I = Img<HD>;
     constexpr int STAGE = 2 * I::BYTES + 512;
@@ -529,7 +543,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
         bf16_t* vp = dqkv + ((size_t)b * S + key[t]) * ld + (H + KV + kvh) * HD;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            uint2 w; w.x = pack2bf(dk[t][dt][0] * scale, dk[t][dt][1] * scale); w.y = pack2bf(dk[t][dt][2] * scale, dk[t][dt][3] * scale);
+            float v0 = dk[t][dt][0] * scale, v1 = dk[t][dt][1] * scale, v2 = dk[t][dt][2] * scale, v3 = dk[t][dt][3] * scale;
+            if (rope) unrope2(rope, key[t], HD, 8 * dt + 2 * g, v0, v1, v2, v3);         // gradient w.r.t. the un-rotated k
+            uint2 w; w.x = pack2bf(v0, v1); w.y = pack2bf(v2, v3);
             *reinterpret_cast<uint2*>(kp + 16 * dt + 4 * g) = w;
             uint2 u; u.x = pack2bf(dv[t][dt][0], dv[t][dt][1]); u.y = pack2bf(dv[t][dt][2], dv[t][dt][3]);
             *reinterpret_cast<uint2*>(vp + 16 * dt + 4 * g) = u;
@@ -548,7 +564,7 @@ static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
 static int g_attn_dkv_map = 3, g_attn_dkv_kt1 = 1, g_attn_q_lpt = 1;   // scheduling switches (csm_set_attn_variant)
 template <int HD, bool BWD, int QT>
 static void launch_q(const void* qkv, void* out, float* lse, const void* dout, float* delta, void* dqkv, int B, int S,
-                     int H, int KV, float scale, hipStream_t stream) {
+                     int H, int KV, float scale, hipStream_t stream, const float* rope = nullptr) {
     constexpr int lds = 2 * 2 * Img<HD>::BYTES;
     auto k = attn_q_kernel<HD, BWD, QT>;
     static bool done = false;
@@ -556,12 +572,12 @@ static void launch_q(const void* qkv, void* out, float* lse, const void* dout, f
     done = true;
     dim3 grid((unsigned)(((S + 64 * QT - 1) / (64 * QT)) * H * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (const bf16_t*)dout, delta,
-                       (bf16_t*)dqkv, S, H, KV, scale, g_attn_q_lpt);
+                       (bf16_t*)dqkv, S, H, KV, scale, g_attn_q_lpt, rope);
 }
 
 template <int HD, int KT>
 static void launch_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
-                       int KV, float scale, hipStream_t stream) {
+                       int KV, float scale, hipStream_t stream, const float* rope = nullptr) {
     constexpr int lds = 2 * (2 * Img<HD>::BYTES + 512);
     auto k = attn_dkv_kernel<HD, KT>;
     static bool done = false;
@@ -569,7 +585,7 @@ static void launch_dkv(const void* qkv, const void* dout, const float* lse, cons
     done = true;
     dim3 grid((unsigned)(((S + 64 * KT - 1) / (64 * KT)) * KV * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, S, H, KV,
-                       scale, g_attn_dkv_map);
+                       scale, g_attn_dkv_map, rope);
 }
 
 static int g_attn_qt_fwd = 2, g_attn_qt_bwd = 1;   // query tiles per wave of the head_dim-64 forward / dQ kernels
@@ -601,8 +617,8 @@ extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S
     return 0;
 }
 
-extern "C" int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                            float* delta_ws, int B, int S, int H, int KV, int HD, hipStream_t stream) {
+static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
+                         const float* rope, int B, int S, int H, int KV, int HD, hipStream_t stream) {
     if (int e = check_attn("csm_attn_bwd", B, S, H, KV, HD)) return e;
     CSM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, "csm_attn_bwd: null pointer");
     const float scale = 1.f / sqrtf((float)HD);
@@ -610,16 +626,28 @@ extern "C" int csm_attn_bwd(const void* qkv, const void* out, const void* dout, 
     void* o = const_cast<void*>(out);
     float* l = const_cast<float*>(lse);
     if (HD == 64) {
-        if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
-        else launch_q<64, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        else launch_q<64, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
-        if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
-        else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
     } else {
-        launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
-        launch_dkv<128, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream);
+        launch_dkv<128, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
     }
     CSM_CHECK_LAUNCH("csm_attn_bwd(dkv)");
     return 0;
+}
+
+extern "C" int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                            float* delta_ws, int B, int S, int H, int KV, int HD, hipStream_t stream) {
+    return attn_bwd_impl(qkv, out, dout, lse, dqkv, delta_ws, nullptr, B, S, H, KV, HD, stream);
+}
+
+extern "C" int csm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                 float* delta_ws, const float* rope_table, int B, int S, int H, int KV, int HD,
+                                 hipStream_t stream) {
+    CSM_REQUIRE(rope_table, "csm_attn_bwd_rope: null table");
+    return attn_bwd_impl(qkv, out, dout, lse, dqkv, delta_ws, rope_table, B, S, H, KV, HD, stream);
 }

@@ -83,6 +83,10 @@ int csm_set_attn_variant(int v); /* scheduling experiments: 0 = defaults; else b
 int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                  float* delta_ws /* [B][H][S] */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
+/* the same with the backward of csm_rope fused into the dQ / dK epilogues (table as for csm_rope, position = row index
+ * inside the sequence): dqkv comes out as the gradient of the UN-rotated projection output, no separate inverse pass. */
+int csm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
+                      const float* rope_table, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 
 /* ---- K7: SwiGLU of torchtune FeedForward: out = silu(gate) * up, gu = gate/up INTERLEAVED ([M][2F]: g0,u0,g1,u1,..) - */
 int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, csm_stream_t stream);

@@ -307,6 +307,14 @@ def test_attention(dev, B, S, H, KV, hd):
     close("attn dq", dqkv[:, :H * hd], gq[:, :H * hd], 2e-2)
     close("attn dk", dqkv[:, H * hd:(H + KV) * hd], gq[:, H * hd:(H + KV) * hd], 2e-2)
     close("attn dv", dqkv[:, (H + KV) * hd:], gq[:, (H + KV) * hd:], 2e-2)
+    # RoPE backward fused into the dQ / dK epilogues == the separate inverse pass (one bf16 rounding fewer), dV untouched
+    from csm.models.model import llama3_rope_table
+    table = llama3_rope_table(S, hd, 500000.0, 32.0).to(dev).contiguous()
+    ops.rope(dqkv, table, S, H + KV, hd, inverse=True)
+    fused = torch.zeros_like(qd)
+    ops.attn_bwd(qd, out, dout.to(dev), lse, fused, delta, B, S, H, KV, hd, rope_table=table)
+    close("attn bwd + rope^T (q, k)", fused[:, :(H + KV) * hd], dqkv[:, :(H + KV) * hd].float(), 1e-2)
+    assert torch.equal(fused[:, (H + KV) * hd:], dqkv[:, (H + KV) * hd:])
 
 
 def test_attention_spike(dev):
