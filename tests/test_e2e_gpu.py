@@ -5,6 +5,7 @@ weights*; gradients (bf16 storage, bf16 activations) within 3e-2 of the tensor's
 indices bit-exact.
 """
 import json
+import math
 import os
 
 import numpy as np
@@ -488,3 +489,50 @@ def test_cli_entry_points(dev, tmp_path, monkeypatch):
     assert rc == 0 and (tmp_path / "l" / "final_lora.safetensors").exists() and (tmp_path / "l" / "final_full.safetensors").exists()
     meta = json.load(open(tmp_path / "l" / "final_lora_metadata.json"))
     assert meta["lora_r"] == 8 and meta["target_modules"] == ["q_proj", "v_proj"]
+
+
+def test_full_size_model_properties(dev):
+    """CSM-1B at BASELINE's sequence length (S=2048), where the CPU oracle is too slow to be the checker: properties that
+    do not depend on the size - bit-exact run-to-run determinism of loss and every gradient (no atomics anywhere in the
+    backward), invariance of the mean loss under duplicating the batch, linearity of the backward in the loss scale, and
+    the 1e-3 north-star bar against the oracle on a prefix that the oracle can still do (S=128)."""
+    from csm.data import SyntheticCSMDataset, collate_variable_length
+    from csm.models.model import Model
+    from csm.training.trainer import csm_1b_args
+    from csm.training.utils import compute_loss
+    m = Model(csm_1b_args(), device=dev, seed=0)
+    m.acoustic_mode = "amortized"
+    ds = SyntheticCSMDataset(2, 2048, seed=77)
+    one = collate_variable_length([ds[0]])
+    rows = torch.arange(0, 2047, 16)                       # fixed decoder rows: the amortised sampler would draw its own
+    m.ensure_grads()
+
+    def run(batch, rows, scale=1.0):
+        m.grad_arena.zero_()
+        m.grad_state.update({k: "zero" for k in m.grad_state})
+        total, det = compute_loss(m, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"], acoustic_rows=rows)
+        (total * scale).backward()
+        return float(total), float(det["semantic_loss"]), float(det["acoustic_loss"]), m.grad_arena.clone()
+
+    t1, s1, a1, g1 = run(one, rows)
+    t2, s2, a2, g2 = run(one, rows)
+    assert math.isfinite(t1) and (t1, s1, a1) == (t2, s2, a2), "loss must be bit-reproducible"
+    assert torch.equal(g1, g2), "every gradient must be bit-reproducible"
+    assert float(g1.float().abs().max()) > 0
+    two = {k: torch.cat([v, v], 0) for k, v in one.items()}
+    t3, s3, a3, g3 = run(two, torch.cat([rows, rows + 2047]))
+    assert rel(s3, s1) < 1e-5 and rel(a3, a1) < 1e-5, "mean loss is invariant under duplicating the batch"
+    gclose("gradient of the duplicated batch", g3, g1.float(), 2e-2)
+    _, _, _, g4 = run(one, rows, scale=0.25)
+    gclose("backward is linear in the loss scale", g4, 0.25 * g1.float(), 2e-2)
+    # oracle on a short prefix with the same weights (bf16 values widened to fp32)
+    S = 128
+    short = {k: v[:, :S] for k, v in one.items()}
+    m.acoustic_mode = "off"
+    with torch.no_grad():
+        tg, _ = compute_loss(m, short["input_tokens"], short["input_masks"], short["target_audio_tokens"])
+    params = {k: v.float().cpu() for k, v in m._views(m.arena).items()}
+    with torch.no_grad():
+        to, _ = O.compute_loss(params, O.csm_1b_cfg(), short["input_tokens"], short["input_masks"], short["target_audio_tokens"],
+                               acoustic_rows="off")
+    assert rel(tg, to) < 1e-3, (float(tg), float(to))
