@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""BASELINE config 5: generate() - AR multi-codebook decode of 10 s of audio (125 frames) on one MI355X, CSM-1B random init.
-The text tokenizer and Mimi cannot be fetched offline: a byte-level stand-in tokenizer and an RVQ-only audio tokenizer
-(random codebooks, csm_rvq_encode / csm_rvq_decode on the GPU) are injected through the Generator constructor."""
+"""BASELINE config 5: generate() - Mimi encode of the context + AR multi-codebook decode of 10 s of audio (125 frames) +
+Mimi decode, on one MI355X, CSM-1B random init.  Neither tokenizer can be fetched offline: the text side is a byte-level
+stand-in, the audio side is the real GPU codec (csm.codec.MimiCodec) with seeded random weights in the Hugging Face
+layout (GEN_CODEC=rvq swaps in the quantiser-only stand-in when transformers is unavailable)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
@@ -44,8 +45,20 @@ class RvqOnlyCodec:
 def main():
     dev = "cuda:0"
     model = Model(csm_1b_args(), device=dev, seed=0)
-    gen = Generator(model, text_tokenizer=ByteTokenizer(), audio_tokenizer=RvqOnlyCodec(dev))
-    ctx = [Segment(0, "hello there", torch.randn(24000, device=dev) * 0.1)]
+    if os.environ.get("GEN_CODEC", "mimi") == "mimi":
+        from transformers import MimiConfig, MimiModel
+        from csm.codec import MimiCodec
+        torch.manual_seed(0)
+        hf = MimiModel(MimiConfig()).eval()
+        with torch.no_grad():
+            for name, buf in hf.named_buffers():
+                if name.endswith("embed_sum"):
+                    buf.copy_(torch.randn(buf.shape))
+        codec = MimiCodec(hf.state_dict(), device=dev)
+    else:
+        codec = RvqOnlyCodec(dev)
+    gen = Generator(model, text_tokenizer=ByteTokenizer(), audio_tokenizer=codec)
+    ctx = [Segment(0, "hello there", torch.randn(5 * 24000, device=dev) * 0.1)]        # 5 s of context audio to tokenise
     frames = int(os.environ.get("GEN_FRAMES", 125))
     for n in (5, frames):
         torch.cuda.synchronize()
