@@ -158,3 +158,58 @@ def test_collate_padding_and_bucketing():
     assert sum(got) == 12
     dl = create_dataloader(ds, batch_size=5, shuffle=False, num_workers=0, pin_memory=False)
     assert [x["input_tokens"].shape[0] for x in dl] == [5, 5, 2]
+
+
+def test_against_reference_fixture():
+    """tests/golden/golden_data.npz holds what the REFERENCE's own data module (loaded by file path in the build container,
+    see tests/golden/make_golden_data.py) produced for these seeded inputs: segment bounds and texts, contextual examples,
+    every dataset item (frame layout, EOS frame, over-length rule) and a collated batch.  Ours must reproduce it exactly,
+    with the tokenizer returning its codes as a list, as a [1,K,T] tensor (Mimi's form, on which the reference itself
+    breaks) or as a [K,T] tensor."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "golden_data.npz"))
+    meta = json.load(open(os.path.join(here, "golden_data_meta.json")))
+    sr = 24000
+    g = torch.Generator().manual_seed(2024)
+    audio = torch.randn(31 * sr + 777, generator=g) * 0.1
+    transcript = " ".join(f"word{i:03d}" for i in range(130))
+    words = [{"word": f"w{i:02d}", "start": 0.45 * i + 0.02, "end": 0.45 * i + 0.40} for i in range(66)]
+    conv_audio = [torch.randn(sr * (1 + i % 3) + 100 * i, generator=g) * 0.1 for i in range(5)]
+    conv_text = [f"turn {i}: the rain in spain stays mainly in the plain" for i in range(5)]
+
+    proc = CSMDataProcessor(sample_rate=sr, segment_duration_ms=10000, overlap_ms=2000)
+    basic = proc._segment_basic(audio, transcript, 5)
+    assert [[e.metadata["start_sample"], e.metadata["end_sample"]] for e in basic] == z["basic_bounds"].tolist()
+    assert [e.text for e in basic] == meta["basic_texts"]
+    al = proc._segment_with_alignments(audio, transcript, 2, {"words": words})
+    assert [[e.metadata["start_sample"], e.metadata["end_sample"]] for e in al] == z["aligned_bounds"].tolist()
+    assert [e.text for e in al] == meta["aligned_texts"]
+    conv = [TrainingExample(t, a, i % 2) for i, (t, a) in enumerate(zip(conv_text, conv_audio))]
+    ctx = ContextualExampleGenerator(max_context_turns=2).create_contextual_examples(conv)
+    assert [len(c["context"]) for c in ctx] == meta["context_lens"]
+    assert [c["context"][0].text if c["context"] else None for c in ctx] == meta["context_first_text"]
+
+    class Tok:
+        def __init__(self, form):
+            self.form = form
+
+        def encode(self, wav):
+            t = math.ceil(wav.shape[-1] / 1920)
+            base = (wav.reshape(-1)[:t].abs() * 1000).long() % 2048
+            codes = (base[None, :] + torch.arange(32)[:, None]) % 2048
+            return {"list": [codes], "b": codes[None], "kt": codes}[self.form]
+
+    for form in ("list", "b", "kt"):
+        for name, max_len in (("full", 2048), ("short", 40)):
+            ds = CSMDataset(ctx, MockTextTokenizer(), Tok(form), max_seq_len=max_len)
+            items = [ds[i] for i in range(len(ds))]
+            for i, it in enumerate(items):
+                assert torch.equal(it["input_tokens"], torch.from_numpy(z[f"{name}_tokens_{i}"]).long()), (form, name, i)
+                assert torch.equal(it["input_masks"], torch.from_numpy(z[f"{name}_masks_{i}"])), (form, name, i)
+                assert torch.equal(it["target_audio_tokens"], torch.from_numpy(z[f"{name}_targets_{i}"]).long()), (form, name, i)
+            if name == "full":
+                b = collate_variable_length(items[1:4])
+                assert torch.equal(b["input_tokens"], torch.from_numpy(z["collate_tokens"]).long())
+                assert torch.equal(b["input_masks"], torch.from_numpy(z["collate_masks"]))
+                assert torch.equal(b["target_audio_tokens"], torch.from_numpy(z["collate_targets"]).long())
