@@ -83,7 +83,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     }
-    constexpr int GROUP_M = 4;
+    // m-tiles per raster group (the tiles an XCD works on at one time are GROUP_M m-tiles x 32 / GROUP_M n-tiles).
+    // tools/probes/group_m_probe.sh: 8 and 16 lose 1-4 %; 2 wins 4 % on the bare N = 16384 GEMM but nothing in the real
+    // step (tools/probes/ab_group_m_step.sh, where that GEMM carries the SwiGLU epilogue).  CSM_GROUP_M pins it for the probes.
+#ifndef CSM_GROUP_M
+#define CSM_GROUP_M 4
+#endif
+    constexpr int GROUP_M = CSM_GROUP_M;
     const int per_group = GROUP_M * g.tiles_n;
     const int grp = id / per_group;
     const int first_m = grp * GROUP_M;
