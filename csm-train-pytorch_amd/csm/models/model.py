@@ -303,6 +303,7 @@ class Model(nn.Module):
         """Allocate the bf16 gradient arena and expose it as ``param.grad`` views."""
         if self.grad_arena is None:
             self.grad_arena = torch.zeros_like(self.arena)
+            self.grad_state.update({k: "zero" for k in self.grad_state})
             gviews = self._views(self.grad_arena)
             for name, p in self.named_parameters():
                 if name in gviews:
