@@ -233,7 +233,10 @@ def main():
             roof = {"bound": "mfma", "kernel": f"gemm_kernel<{dom[0]}>", "achieved": round(dom[1]["tflops"], 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                    "operand_bytes_per_launch": round(dom[1]["operand_bytes_per_launch"]), "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
+                    "operand_bytes_per_launch": round(dom[1]["operand_bytes_per_launch"]),
+                    "peak_note": "dense bf16 MFMA peak of the micro-architecture guide; the chip is power limited on non-zero data: a "
+                                 "register-only MFMA loop reaches 1.56-1.85 PFLOP/s on random bf16 operands (tools/probes/mfma_shape_probe.hip)",
+                    "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
                     "all_gemm_variants": {k: {"tflops": round(v["tflops"], 1), "ms_per_step": round(v["time_ms"], 2),
                                               "launches": v["launches"]} for k, v in kinds.items()}}
         out = {
