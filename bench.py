@@ -140,6 +140,9 @@ def cpu_baseline(model, cfg_fn, seq, seed, sw, aw):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON result): everything incidental - logger handlers created from here on,
+    # library prints - goes to stderr
+    real_stdout, sys.stdout = sys.stdout, sys.stderr
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -262,7 +265,7 @@ def main():
             out["cpu_baseline"] = cb
             out["parity_check"] = {"what": "loss of the same weights/batch: HIP bf16 path vs CPU fp32 oracle", "cpu_loss": cpu_loss,
                                    "gpu_loss": float(gl), "rel_diff": abs(float(gl) - cpu_loss) / abs(cpu_loss)}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
