@@ -175,7 +175,8 @@ def main():
         args = csm_1b_args()
     model = Model(args, device=f"cuda:{local}", seed=0)          # random init, same on every rank
     model.acoustic_mode = {"A": "off", "B": "all", "C": "amortized"}[a.mode]
-    tr = CSMTrainer("", os.path.join(ROOT, "gpurun_out", f"bench_rank{rank}"), device=f"cuda:{local}")
+    import tempfile
+    tr = CSMTrainer("", tempfile.mkdtemp(prefix=f"csm_bench_rank{rank}_"), device=f"cuda:{local}")   # trainer wants an output dir
     tr.logger.setLevel(30)
     tr.model = model
     if a.lora:
