@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBPS = 8000.0           # HBM3E (same table)
 
 
 def parse():
@@ -84,11 +85,31 @@ class GemmTimer:
             timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1, batch * (2.0 * (M * K + N * K) + esz * M * N)))
             return out
 
-        ops.gemm, ops.linear_swiglu_fwd, ops.linear_dx_swiglu_bwd = timed, fused_fwd, fused_bwd
+        self.orig_adamw = ops.adamw_step
+        self.hbm = []
+
+        def adamw(master, m, v, param, grad, *args, zero_grad=False, **kw):     # HBM-bound side of the step, timed the same way
+            e0, e1 = ev()
+            e0.record(); r = timer.orig_adamw(master, m, v, param, grad, *args, zero_grad=zero_grad, **kw); e1.record()
+            timer.hbm.append(((28 + (2 if zero_grad else 0)) * master.numel(), e0, e1))
+            return r
+
+        ops.gemm, ops.linear_swiglu_fwd, ops.linear_dx_swiglu_bwd, ops.adamw_step = timed, fused_fwd, fused_bwd, adamw
         return self
 
     def __exit__(self, *a):
         self.ops.gemm, self.ops.linear_swiglu_fwd, self.ops.linear_dx_swiglu_bwd = self.orig, self.orig_fwd, self.orig_bwd
+        self.ops.adamw_step = self.orig_adamw
+
+    def adamw_summary(self):
+        torch.cuda.synchronize()
+        if not self.hbm:
+            return None
+        nbytes = sum(b for b, _, _ in self.hbm)
+        sec = sum(e0.elapsed_time(e1) for _, e0, e1 in self.hbm) * 1e-3
+        return {"kernel": "adamw_kernel", "bound": "hbm", "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBPS, 4), "ms_per_step": round(sec * 1e3, 3),
+                "algorithmic_bytes_per_step": nbytes}
 
     def summary(self):
         torch.cuda.synchronize()
@@ -252,6 +273,9 @@ def main():
                        + (" (semantic CE + depth decoder on 1/16 of frames)" if a.mode == "C" else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq, "parallelism": f"dp{world}"},
             "codebook_tokens_per_s": round(world * cb_tokens / (dt / a.steps), 1),   # secondary: 32 per audio frame + 1 per text token
+            "mfma_utilisation_step": round(sum(v["flop"] for v in kinds.values()) / (dt / a.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+            if kinds else None,                                # GEMM FLOP of one step / step time / dense peak (attention not counted)
+            "hbm_kernel": gt.adamw_summary() if gt is not None else None,
             "loss": float(loss), "step_ms": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}, "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
