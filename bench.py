@@ -19,6 +19,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
+# the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (already exported on the
+# build and GPU boxes; kept here so that a bare `torchrun bench.py` works too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 

@@ -23,6 +23,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Read RANK / WORLD_SIZE / LOCAL_RANK (torchrun) and create the process group.  Returns (rank, world, local)."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL buffer sharing); too late if HIP is already up
     if world > 1 and not dist.is_initialized():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
