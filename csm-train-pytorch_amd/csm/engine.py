@@ -456,6 +456,16 @@ class Engine:
         st.cur += 1
         return self._decode_frame(st, tokens, tokens_mask, temperature, topk, noise)
 
+    @torch.no_grad()
+    def generate_first_frames(self, tokens_list, masks_list, temperature, topk, noise=None):
+        """Batched generation (up to 4 utterances): prefill B prompts of different lengths and sample the
+        first frame of each; later frames go through ``generate_frame`` with ``[B, 1, K+1]`` tokens and a non-zero
+        ``input_pos``, exactly as for one utterance."""
+        m = self.m
+        st = m._decode_state = DecodeState(self, len(tokens_list))
+        last_h = st.prefill_ragged(tokens_list, masks_list)
+        return self._frame_tail(st, last_h, temperature, topk, noise)
+
     def _decode_frame(self, st, tokens, tokens_mask, temperature, topk, noise):
         """One decode frame with no host-side dependence on device data: this is the body a HIP graph captures."""
         last_h = st.backbone_step(tokens, tokens_mask)
@@ -558,6 +568,15 @@ class _DecodeStack:
             self.k[i][:, :, :S] = qkv[:, :, H * hd:(H + KV) * hd].reshape(B, S, KV, hd).permute(0, 2, 1, 3)
             self.v[i][:, :, :S] = qkv[:, :, (H + KV) * hd:].reshape(B, S, KV, hd).permute(0, 2, 1, 3)
 
+    def fill_row(self, acts, b, S):
+        """The same for ONE sequence (a [1, S] prefill) into batch row ``b`` of the caches: ragged batched prompts."""
+        c = self.stack.c
+        H, KV, hd = c.num_heads, c.num_kv_heads, c.head_dim
+        for i, a in enumerate(acts):
+            qkv = a["qkv"].view(S, -1)
+            self.k[i][b, :, :S] = qkv[:, H * hd:(H + KV) * hd].reshape(S, KV, hd).permute(1, 0, 2)
+            self.v[i][b, :, :S] = qkv[:, (H + KV) * hd:].reshape(S, KV, hd).permute(1, 0, 2)
+
     def step(self, x: torch.Tensor, final_norm: bool = True) -> torch.Tensor:
         """One position per batch row at ``self.pos`` (device int32).  x [B, d] -> final-normed hidden [B, d]
         (``final_norm=False``: the un-normed residual stream, for a caller that fuses the norm into its next product)."""
@@ -620,6 +639,27 @@ class DecodeState:
         self.bb.pos.fill_(S - 1)
         self.cur = S - 1                       # host mirror of the device-side position (no sync per frame)
         return hidden.view(B, S, -1)[:, -1, :].contiguous()
+
+    def prefill_ragged(self, tokens_list, masks_list):
+        """Prompts of different lengths, one per batch row: each is prefilled on its own ([1, S_b] through the training
+        forward) into its row of the caches; positions are per row from then on (``pos`` is a device vector)."""
+        e, m = self.e, self.e.m
+        last = []
+        for b, (tk, mk) in enumerate(zip(tokens_list, masks_list)):
+            S = tk.shape[0]
+            if S > m.bb.max_seq_len:
+                raise ValueError("prompt longer than max_seq_len")
+            tk = tk.to(device=m.device, dtype=torch.int64).contiguous()
+            mk = mk.to(device=m.device, dtype=torch.uint8).contiguous()
+            h0 = torch.empty(S, m.bb.embed_dim, dtype=BF16, device=m.device)
+            ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, m.args.audio_vocab_size)
+            hidden = e.backbone.forward(h0, 1, S, True)
+            self.bb.fill_row(e.backbone.acts, b, S)
+            e.backbone.acts = []
+            self.bb.pos[b] = S - 1
+            last.append(hidden[-1])
+            self.cur = max(self.cur, S - 1)
+        return torch.stack(last).contiguous()
 
     def backbone_step(self, tokens, masks):
         m = self.e.m

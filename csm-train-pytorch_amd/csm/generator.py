@@ -131,6 +131,60 @@ class Generator:
         codes = torch.stack(samples).permute(1, 2, 0).long()
         return self._audio_tokenizer.decode(codes).squeeze(0).squeeze(0)
 
+    @torch.inference_mode()
+    def generate_batch(self, texts: List[str], speakers: List[int], contexts: List[List[Segment]],
+                       max_audio_length_ms: float = 90_000, temperature: float = 0.9, topk: int = 50,
+                       eos_check_every: int = 8) -> List[torch.Tensor]:
+        """``generate`` for up to 4 utterances at once (not in the reference, whose loop is single-utterance): the prompts
+        (different lengths) are prefilled one by one into their rows of the KV caches, then every decode frame advances all
+        rows together - the decode kernels share each weight load between the batch rows, so B utterances cost about as
+        much as one.  A row stops contributing at its own EOS frame; the loop ends when every row has one."""
+        B = len(texts)
+        if not (1 <= B <= 4 and len(speakers) == B and len(contexts) == B):
+            raise ValueError("generate_batch takes 1..4 utterances with one speaker id and one context list each")
+        self._model.reset_caches()
+        max_audio_frames = int(max_audio_length_ms / 80)
+        K = self._model.args.audio_num_codebooks
+        toks, msks = [], []
+        for text, spk, ctx in zip(texts, speakers, contexts):
+            t_, m_ = [], []
+            for seg in ctx:
+                t, m = self._tokenize_segment(seg)
+                t_.append(t)
+                m_.append(m)
+            t, m = self._tokenize_text_segment(text, spk)
+            t_.append(t)
+            m_.append(m)
+            toks.append(torch.cat(t_, 0).long().to(self.device))
+            msks.append(torch.cat(m_, 0).bool().to(self.device))
+            if toks[-1].size(0) >= self._model.bb.max_seq_len - max_audio_frames:
+                raise ValueError(f"Inputs too long, must be below max_seq_len - max_audio_frames: {self._model.bb.max_seq_len - max_audio_frames}")
+        frames = [self._model.engine.generate_first_frames(toks, msks, temperature, topk)]          # [B, K] each
+        mask = torch.cat([torch.ones(B, K, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool)], 1).unsqueeze(1).to(self.device)
+        pad = torch.zeros(B, 1, dtype=torch.long, device=self.device)
+        pos = torch.ones(B, 1, dtype=torch.long, device=self.device)       # only "not the prompt" matters: positions live on the device
+        eos_at = [None] * B
+        step = max(1, int(eos_check_every))
+        for i in range(1, max_audio_frames + 1):
+            if i % step == 0 or i == max_audio_frames:
+                allz = (torch.stack(frames, 1) == 0).all(dim=2).cpu()                               # [B, frames so far]
+                for b in range(B):
+                    hit = allz[b].nonzero()
+                    eos_at[b] = int(hit[0]) if hit.numel() else None
+                if all(e is not None for e in eos_at) or i == max_audio_frames:
+                    break
+            tokens = torch.cat([frames[-1].long(), pad], dim=1).unsqueeze(1)
+            frames.append(self._model.generate_frame(tokens, mask, pos, temperature, topk))
+        out = []
+        codes_all = torch.stack(frames, 2).long()                                                    # [B, K, T]
+        for b in range(B):
+            n = eos_at[b] if eos_at[b] is not None else min(len(frames), max_audio_frames)
+            if n == 0:
+                out.append(torch.zeros(0, device=self.device))
+            else:
+                out.append(self._audio_tokenizer.decode(codes_all[b:b + 1, :, :n]).squeeze(0).squeeze(0))
+        return out
+
     def save_wav(self, path: str, audio: torch.Tensor):
         """16-bit PCM writer (torchaudio is not available in this image)."""
         import wave

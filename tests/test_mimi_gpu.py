@@ -108,6 +108,9 @@ def test_mimi_as_generator_tokenizer(dev):
     m.generate_frame = lambda *a, _c=calls, **k: (_c.append(1), script[len(_c) - 1])[1]
     assert gen.generate("ok", 1, [], max_audio_length_ms=800).numel() == 0
     del m.generate_frame
+    # batched generation: two utterances, different contexts; each row ends at its own EOS (none here within 5 frames)
+    outs = gen.generate_batch(["ok", "hello there"], [1, 0], [[seg], []], max_audio_length_ms=400)
+    assert len(outs) == 2 and all(o.dim() == 1 and o.numel() % 1920 == 0 and torch.isfinite(o).all() for o in outs)
 
 
 def test_cli_trains_from_raw_audio(dev, tmp_path, monkeypatch):

@@ -68,6 +68,18 @@ def main():
         dt = time.time() - t0
         print(f"{n} frames requested: {audio.numel() / 24000:.2f} s of audio in {dt:.2f} s -> {audio.numel() / 1920 / dt:.1f} frames/s "
               f"({audio.numel() / 24000 / dt:.2f}x real time)")
+    nb = int(os.environ.get("GEN_BATCH", 4))
+    if nb > 1:
+        texts = [f"utterance number {i}: the quick brown fox jumps over the lazy dog" for i in range(nb)]
+        ctxs = [ctx if i % 2 == 0 else [] for i in range(nb)]
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            outs = gen.generate_batch(texts, list(range(nb)), ctxs, max_audio_length_ms=80 * frames)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+        tot = sum(o.numel() for o in outs)
+        print(f"batch of {nb}: {tot / 24000:.2f} s of audio in {dt:.2f} s -> {tot / 1920 / dt:.1f} frames/s aggregate ({tot / 24000 / dt:.2f}x real time)")
 
 
 if __name__ == "__main__":
