@@ -159,3 +159,40 @@ def test_cli_trains_from_raw_audio(dev, tmp_path, monkeypatch):
                          "--text-tokenizer", str(tmp_path / "tok"), "--epochs", "1", "--batch-size", "2", "--accumulation-steps", "1",
                          "--num-workers", "0", "--val-split", "0.34", "--acoustic-mode", "all", "--ignore-padding", "--val-every", "1"])
     assert rc == 0 and (tmp_path / "out" / "final_latest.pt").exists()
+
+
+def test_cli_generate(dev, tmp_path, monkeypatch):
+    """csm-generate front end (reference cli/generate.py flags): context WAV -> Segment, generate, 16-bit WAV out.  The
+    1B checkpoint loader is swapped for a tiny random model; codec and tokenizer are the real code paths."""
+    import wave
+    import numpy as np
+    from csm.cli import generate as cli_gen
+    from csm.codec import MimiCodec
+    from csm.generator import Generator
+    from csm.models.model import Model, ModelArgs
+
+    class Tok:
+        def encode(self, text):
+            return [1] + [3 + (b % 200) for b in text.encode()] + [2]
+
+    def tiny_loader(ckpt, device, mimi_weights=None, tokenizer_path=None):
+        assert ckpt == "ckpt.pt" and mimi_weights == "m.safetensors" and tokenizer_path == "tokdir"
+        m = Model(ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", 300, 2051, 32), device="cuda", seed=2)
+        return Generator(m, text_tokenizer=Tok(), audio_tokenizer=MimiCodec(_hf_model(5).state_dict(), device="cuda"))
+
+    monkeypatch.setattr(cli_gen, "load_csm_1b", tiny_loader)
+    x = (0.2 * np.random.default_rng(1).standard_normal(16000)).clip(-1, 1)
+    with wave.open(str(tmp_path / "ctx.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((x * 32767).astype("<i2").tobytes())
+    out = tmp_path / "sub" / "out.wav"
+    rc = cli_gen.main(["--model-path", "ckpt.pt", "--text", "hello", "--voice", "warm", "--output", str(out),
+                       "--context-audio", str(tmp_path / "ctx.wav"), "--context-text", "hi there", "--context-speaker", "2",
+                       "--max-audio-length-ms", "320", "--mimi-weights", "m.safetensors", "--text-tokenizer", "tokdir"])
+    assert rc == 0 and out.exists()
+    with wave.open(str(out), "rb") as w:
+        assert w.getframerate() == 24000 and w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getnframes() % 1920 == 0
+    with pytest.raises(ValueError):
+        cli_gen.main(["--model-path", "ckpt.pt", "--text", "x", "--context-audio", str(tmp_path / "ctx.wav"),
+                      "--mimi-weights", "m.safetensors", "--text-tokenizer", "tokdir"])
+
