@@ -589,11 +589,16 @@ static void launch_dkv(const void* qkv, const void* dout, const float* lse, cons
 }
 
 static int g_attn_qt_fwd = 2, g_attn_qt_bwd = 1;   // query tiles per wave of the head_dim-64 forward / dQ kernels
+static int g_attn_gen2 = 1;                          // head_dim 64: second-generation kernels of attention64.hip (bit0 fwd, bit1 bwd)
+int csm_attn64_fwd_launch(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, hipStream_t stream);
 extern "C" int csm_set_attn_variant(int v) {
     // 0 restores the defaults.  Otherwise an experiment word: bits 0..1 / 2..3 query tiles per wave of the head_dim-64
     // forward / dQ kernel (1 | 2; 0 = 1); bits 4..5 dK/dV work order (0 plain, 1 / 2 complementary pairing, 3 heaviest key blocks first);
     // bit 6 dK/dV key tile (1: 64 keys per workgroup, 0: 128); bit 7 forward / dQ work order heaviest q-blocks first.
+    // bits 8..9: 0 = second-generation head_dim-64 kernels (attention64.hip; the default), 1 = first generation forward,
+    // 2 = first generation backward, 3 = both first generation (A/B reference).
     if (v == 0) v = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7);
+    g_attn_gen2 = 3 & ~((v >> 8) & 3);
     g_attn_qt_fwd = (v & 3) == 2 ? 2 : 1;
     g_attn_qt_bwd = ((v >> 2) & 3) == 2 ? 2 : 1;
     g_attn_dkv_map = (v >> 4) & 3;
@@ -607,7 +612,9 @@ extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S
     if (int e = check_attn("csm_attn_fwd", B, S, H, KV, HD)) return e;
     CSM_REQUIRE(qkv && out && lse, "csm_attn_fwd: null pointer");
     const float scale = 1.f / sqrtf((float)HD);
-    if (HD == 64) {
+    if (HD == 64 && (g_attn_gen2 & 1)) {
+        csm_attn64_fwd_launch(qkv, out, lse, B, S, H, KV, stream);
+    } else if (HD == 64) {
         if (S > 64 && g_attn_qt_fwd == 2) launch_q<64, false, 2>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
         else launch_q<64, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
     } else {

@@ -1,0 +1,310 @@
+// head_dim-64 causal GQA flash attention for gfx950, second generation (the backbone's shape: S = 2048, 32 q / 8 kv heads).
+//
+// Same contract as attention.hip (which keeps head_dim 128 and stays the A/B reference for head_dim 64):
+// replaces torchtune MultiHeadAttention -> F.scaled_dot_product_attention with the mask of reference
+// src/csm/models/model.py:59-76 / src/csm/training/utils.py:90-91 (positions arange(S) => plain causal).
+//
+// What is different from attention.hip, and why (all of it follows from hd = 64 being VALU-bound on the softmax):
+//   * mfma_f32_32x32x16_bf16 instead of 16x16x32: half the MFMA instructions for the same FLOPs, and an MFMA holds the SIMD's
+//     vector issue port for 8 of its 32 cycles instead of 8 of 16 - the freed issue slots go to exp / fma / cvt.
+//   * S^T = K Q^T with the query on the lane (32 queries per wave): max / sum / lse are per-lane scalars, one
+//     v_permlane32_swap joins the two lane halves; the P^T accumulators are the B operand of the PV product as they
+//     stand (k order 16s + 8(j>>2) + 4h + (j&3), matched by the transposed V reads).
+//   * the row sum l rides on the matrix pipe (an all-ones A operand), which has slack here, instead of 32 v_add per block.
+//   * the S^T tile of key block j+1 is computed while block j goes through the softmax (two named accumulator sets,
+//     loop unrolled by two), so the wave always has independent MFMA and VALU work to issue.
+//   * K / V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane) into a 3-stage ring, issued a whole iteration ahead:
+//     no staging registers, no ds_write, one barrier per key block.
+//   * ONE LDS image layout for every tile: 128-B rows, 16-B chunk c of row r at chunk c ^ f(r),
+//     f(r) = ((r>>1)&1)<<2 | (r>>2)&3 - conflict-free both for ds_read_b128 row fragments of a 32-row MFMA operand and
+//     for ds_read_b64_tr_b16 transposed fragments (checked against the gfx950 banking rules: MI355X_MICROARCH.md, LDS).
+//     The DMA writes LDS linearly, so the XOR goes on the per-lane SOURCE address.
+//   * O leaves through LDS so that every store instruction writes whole 128-B rows.
+#include "common.h"
+#include <math.h>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int TILE = 64 * 128;          // one 64-row x 64-column bf16 image
+constexpr int STAGE = 2 * TILE;         // K image + V image
+constexpr int NSTAGE = 3;
+
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// max over the two lane halves (lanes l and l ^ 32 hold the same query)
+__device__ __forceinline__ float halves_max(float x) {
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float a;
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(q[0])), "v"(__uint_as_float(q[1])));
+    return a;
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x4 tr_read(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 row_read(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n) : "memory")
+
+__device__ __forceinline__ bf16x8 pack8f(const f32x16& a, int s) {   // registers 8s .. 8s+7 -> one k-step's B fragment
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(a[8 * s + j]);
+    return r;
+}
+
+// 1-D XCD-aware work order shared by the kernels of this file: a contiguous run of (batch, kv-head) pairs per XCD, and
+// inside a run the heaviest causal blocks first (see attention.hip for the reasoning).  Returns (pair, head-in-group, block).
+__device__ __forceinline__ void work_item(int nblk, int rep, int& pair, int& hh, int& blk) {
+    const int per_pair = rep * nblk;
+    const int T = gridDim.x, id = blockIdx.x, xcd = id & 7, within = id >> 3;
+    const int q8 = T >> 3, r8 = T & 7;
+    const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    pair = nid / per_pair;
+    int local = nid % per_pair;
+    const int run = (xcd < r8) ? q8 + 1 : q8;
+    const int base = nid - within;
+    if (run % per_pair == 0 && base % per_pair == 0) {
+        const int ncomb = (run / per_pair) * rep;
+        const int comb = within % ncomb;
+        pair = base / per_pair + comb / rep;
+        local = (comb % rep) * nblk + within / ncomb;
+    }
+    hh = local / nblk;
+    blk = nblk - 1 - (local % nblk);
+}
+
+// one wave's 2 KiB share (pieces 2w, 2w+1) of a 64-row tile, by LDS-DMA
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ P, int ld, int S, int row0, char* img, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = 2 * wave + i;
+        const int row = 8 * j + (lane >> 3);
+        int gr = row0 + row;
+        gr = gr < S ? gr : S - 1;
+        const int lc = (lane & 7) ^ swz(row);
+        const bf16_t* src = P + (size_t)gr * ld + lc * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(img + j * 1024), 16, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: workgroup = 128 queries of one (b, h) = 4 waves x 32 queries; key blocks of 64
+__global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int S, int H, int KV, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rep = H / KV;
+    const int nqblk = (S + 127) / 128;
+    int pair, hh, qb;
+    work_item(nqblk, rep, pair, hh, qb);
+    const int kvh = pair % KV, b = pair / KV;
+    const int hq = kvh * rep + hh;
+    const int ld = (H + 2 * KV) * 64;
+    const bf16_t* Qp = qkv + (size_t)b * S * ld + hq * 64;
+    const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * 64;
+    const bf16_t* Vp = qkv + (size_t)b * S * ld + (H + KV + kvh) * 64;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q_base = qb * 128;
+    const int qw = q_base + 32 * wave;                 // first query of this wave
+    const int qrow = qw + r;
+    const int qc = qrow < S ? qrow : S - 1;
+    const float c2 = scale * 1.4426950408889634f;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qp + (size_t)qc * ld + 16 * ks + 8 * h);
+
+    // per-lane LDS offsets inside a stage.  K row fragments: row 32t + r, chunk 2ks + h (t -> immediate offset 4096 t)
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    unsigned koff[4];
+    {
+        const int fx = swz(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ fx) << 4);
+    }
+    // V transposed fragments for (dt, u): k-rows 32t + 16s + 8u + 4(g>>1) + q, columns 32dt + 16(g&1) + 4p .. +3
+    unsigned voff[2][2];
+    {
+        const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = 8 * u + 4 * (g >> 1) + q4;
+                const int ch = 4 * dt + 2 * (g & 1) + (p >> 1);
+                voff[dt][u] = TILE + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
+            }
+    }
+
+    int lastq = q_base + 127;
+    lastq = lastq < S ? lastq : S - 1;
+    const int nkb = lastq / 64 + 1;                     // key blocks (64 keys) of the workgroup
+    int lastw = qw + 31;
+    lastw = lastw < S ? lastw : S - 1;
+    const int ntw = qw < S ? lastw / 32 + 1 : 0;        // key TILES (32 keys) this wave needs
+
+    auto stage_ptr = [&](int st) { return smem + st * STAGE; };
+    auto issue = [&](int kb, int st) {
+        dma_tile(Kp, ld, S, kb * 64, stage_ptr(st), wave, lane);
+        dma_tile(Vp, ld, S, kb * 64, stage_ptr(st) + TILE, wave, lane);
+    };
+
+    f32x16 o0, o1, lacc, zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; lacc[i] = 0.f; zero16[i] = 0.f; }
+    float m = -INFINITY;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define EXP2(S_, I_) { S_[I_] = fexp2(fmaf(S_[I_], c2, nb)); S_[I_ + 1] = fexp2(fmaf(S_[I_ + 1], c2, nb)); }
+    // One 32-key tile of one wave.  c: S^T of this tile (computed one step earlier); n receives S^T of the next tile (NEXT),
+    // whose K rows sit at LDS address an.  Instruction order is pinned (sched_barrier between groups): an MFMA is followed
+    // by the exp2 of two scores (8 + 2 x 12 issue cycles per 32-cycle MFMA), so matrix pipe and VALU run together inside
+    // one wave instead of relying on the SIMD's other wave being in the opposite phase:
+    //   R1  4 MFMA  S^T(next tile)         |  exp2 of scores 0..7   (k-step 0 of the PV product)
+    //   R2  3 MFMA  row sum + PV, k-step 0 |  exp2 of scores 8..15
+    //   R3  3 MFMA  row sum + PV, k-step 1
+    // TOFF = byte offset of the tile's 32 rows inside the K / V images (0 or 4096).
+    auto step = [&](auto next_tag, auto toff_tag, int key0, unsigned a, unsigned an, f32x16& c, f32x16& n) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        constexpr int TOFF = decltype(toff_tag)::value, NOFF = 4096 - TOFF;
+        bf16x8 k0, k1, k2, k3;
+        if (NEXT) { k0 = row_read<NOFF>(an + koff[0]); k1 = row_read<NOFF>(an + koff[1]); k2 = row_read<NOFF>(an + koff[2]); k3 = row_read<NOFF>(an + koff[3]); }
+        // V^T fragments: [k-step s][column half dt][row group u]
+        const bf16x4 v000 = tr_read<TOFF>(a + voff[0][0]), v001 = tr_read<TOFF>(a + voff[0][1]);
+        const bf16x4 v010 = tr_read<TOFF>(a + voff[1][0]), v011 = tr_read<TOFF>(a + voff[1][1]);
+        const bf16x4 v100 = tr_read<TOFF + 2048>(a + voff[0][0]), v101 = tr_read<TOFF + 2048>(a + voff[0][1]);
+        const bf16x4 v110 = tr_read<TOFF + 2048>(a + voff[1][0]), v111 = tr_read<TOFF + 2048>(a + voff[1][1]);
+        if (key0 + 31 > qw) {                           // the tile crosses this wave's diagonal (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (key0 + (i & 3) + 8 * (i >> 2) + 4 * h > qrow) c[i] = -INFINITY;
+        }
+        float x0 = vmax3(c[0], c[1], c[2]), x1 = vmax3(c[3], c[4], c[5]), x2 = vmax3(c[6], c[7], c[8]), x3 = vmax3(c[9], c[10], c[11]);
+        x0 = vmax3(x0, c[12], c[13]); x1 = vmax3(x1, c[14], c[15]);
+        x0 = vmax3(x0, x1, x2);
+        const float m_new = halves_max(vmax3(x0, x3, m));
+        if (!__all(m_new == m)) {                       // rescale only when some query's running max moved
+            const float alpha = fexp2((m - m_new) * c2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            lacc[0] *= alpha;                           // every row of lacc is the same sum; only row 0 is read
+            m = m_new;
+        }
+        const float nb = -m * c2;
+        // ---- R1
+        if (NEXT) {
+            LGKM_WAIT(8);                                // the K fragments have landed (the 8 V reads may still fly)
+            n = MFMA32(k0, qf[0], zero16); SB(); EXP2(c, 0) SB();
+            n = MFMA32(k1, qf[1], n); SB(); EXP2(c, 2) SB();
+            n = MFMA32(k2, qf[2], n); SB(); EXP2(c, 4) SB();
+            n = MFMA32(k3, qf[3], n); SB(); EXP2(c, 6) SB();
+        } else {
+            EXP2(c, 0) EXP2(c, 2) EXP2(c, 4) EXP2(c, 6)
+        }
+        const bf16x8 p0 = pack8f(c, 0);
+        LGKM_WAIT(0);
+        // ---- R2
+        lacc = MFMA32(ones, p0, lacc); SB(); EXP2(c, 8) SB();
+        o0 = MFMA32(cat4(v000, v001), p0, o0); SB(); EXP2(c, 10) SB();
+        o1 = MFMA32(cat4(v010, v011), p0, o1); SB(); EXP2(c, 12) EXP2(c, 14) SB();
+        const bf16x8 p1 = pack8f(c, 1);
+        // ---- R3
+        lacc = MFMA32(ones, p1, lacc);
+        o0 = MFMA32(cat4(v100, v101), p1, o0);
+        o1 = MFMA32(cat4(v110, v111), p1, o1);
+    };
+#undef EXP2
+
+    issue(0, 0);
+    if (nkb > 1) { issue(1, 1); VM_WAIT(4); } else { VM_WAIT(0); }
+    __builtin_amdgcn_s_barrier();
+
+    using T1 = std::integral_constant<bool, true>;
+    using T0 = std::integral_constant<bool, false>;
+    using OFF0 = std::integral_constant<int, 0>;
+    using OFF1 = std::integral_constant<int, 4096>;
+    f32x16 sa, sb;
+    if (ntw > 0) {                                       // S^T of tile 0
+        bf16x8 k0 = row_read<0>(sbase + koff[0]), k1 = row_read<0>(sbase + koff[1]), k2 = row_read<0>(sbase + koff[2]), k3 = row_read<0>(sbase + koff[3]);
+        LGKM_WAIT(0);
+        sa = MFMA32(k0, qf[0], zero16); sa = MFMA32(k1, qf[1], sa); sa = MFMA32(k2, qf[2], sa); sa = MFMA32(k3, qf[3], sa);
+    }
+    int st = 0;                                          // stage of block kb
+    for (int kb = 0; kb < nkb; ++kb) {
+        VM_WAIT(0);                                      // block kb+1 (issued one iteration ago) has landed
+        __builtin_amdgcn_s_barrier();                    // ... for every wave; and stage (kb+2)%3 is no longer read
+        const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+        if (kb + 2 < nkb) issue(kb + 2, st2);
+        const unsigned a = sbase + st * STAGE, an = sbase + st1 * STAGE;
+        // tile 2kb (set a; next = tile 2kb+1 of the same block -> set b)
+        // (S^T of the following tile is computed even when the wave will not use it - at most one wasted tile per wave -
+        // so that the loop body has a single code path: two versions of a step merge ~100 live registers through copies)
+        if (2 * kb < ntw) step(T1{}, OFF0{}, kb * 64, a, a, sa, sb);
+        // tile 2kb+1 (set b; next = tile 0 of block kb+1 -> set a)
+        if (2 * kb + 1 < ntw) step(T1{}, OFF1{}, kb * 64 + 32, a, an, sb, sa);
+        st = st1;
+    }
+#undef SB
+
+    // ---- epilogue: O^T registers -> LDS [q][d] (144-B rows) -> whole 128-B rows to HBM
+    __builtin_amdgcn_s_barrier();                        // every wave is done with the stages
+    {
+        const float l = lacc[0];
+        const float inv = 1.f / l;
+        char* ob = smem + wave * (32 * 144);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            uint2 w0, w1;
+            w0.x = pack2bf(o0[4 * gq] * inv, o0[4 * gq + 1] * inv); w0.y = pack2bf(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+            w1.x = pack2bf(o1[4 * gq] * inv, o1[4 * gq + 1] * inv); w1.y = pack2bf(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+            *reinterpret_cast<uint2*>(ob + r * 144 + (8 * gq + 4 * h) * 2) = w0;           // d = 8 gq + 4h .. +3
+            *reinterpret_cast<uint2*>(ob + r * 144 + (32 + 8 * gq + 4 * h) * 2) = w1;      // d = 32 + ...
+        }
+        if (h == 0 && qrow < S) lse[((size_t)b * H + hq) * S + qrow] = m * scale + logf(l);
+        // (wave-private LDS region: a wave's own LDS operations execute in order, no wait or barrier needed)
+        bf16_t* op = out + ((size_t)b * S) * (H * 64) + hq * 64;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = 8 * pass + (lane >> 3);
+            const U4 v = *reinterpret_cast<const U4*>(ob + row * 144 + (lane & 7) * 16);
+            if (qw + row < S) *reinterpret_cast<U4*>(op + (size_t)(qw + row) * (H * 64) + (lane & 7) * 8) = v;
+        }
+    }
+}
+
+}  // namespace
+
+int csm_attn64_fwd_launch(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, hipStream_t stream) {
+    const float scale = 0.125f;
+    const int lds = NSTAGE * STAGE;
+    dim3 grid((unsigned)(((S + 127) / 128) * H * B)), block(256);
+    hipLaunchKernelGGL(attn64_fwd_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, H, KV, scale);
+    return 0;
+}

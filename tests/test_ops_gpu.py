@@ -280,7 +280,7 @@ def _attn_ref(qkv, B, S, H, KV, hd):
 
 
 @pytest.mark.parametrize("B,S,H,KV,hd", [(1, 64, 1, 1, 64), (2, 200, 4, 2, 64), (1, 512, 8, 2, 64), (3, 32, 2, 1, 128),
-                                        (2, 100, 4, 2, 128)])
+                                        (2, 100, 4, 2, 128), (1, 31, 2, 2, 64), (2, 1000, 4, 1, 64), (1, 2048, 4, 1, 64)])
 def test_attention(dev, B, S, H, KV, hd):
     from csm.hip import ops
     g = torch.Generator().manual_seed(S + hd)

@@ -21,8 +21,8 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
-for v in [int(x) for x in os.environ.get('AB_VARIANTS', '5,0,5,0').split(',')]:
+for v in [int(x) for x in os.environ.get('AB_VARIANTS', '768,0,768,0').split(',')]:
     ops.lib.csm_set_attn_variant(v)
     tf = timeit(lambda: ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd))
     tb = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, dqkv, delta, B, S, H, KV, hd))
-    print(f"QT={v}: fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF/s | bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF/s (2.5x fwd flop)")
+    print(f"variant={v} (768 = first-generation kernels, 0 = default): fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF/s | bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF/s (2.5x fwd flop)")
