@@ -27,7 +27,16 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// experiment switches for tools/probes/ablate_attn64.sh (never set in the shipped build): what bounds the forward loop?
+// bit0: no exp2; bit1: no barrier / DMA wait in the loop; bit2: no LDS fragment reads in the loop; bit3: no MFMA in the loop;
+// bit4: no running-max update
+#ifndef CSM_ATT64_ABLATE
+#define CSM_ATT64_ABLATE 0
+#endif
+constexpr bool AB_EXP = CSM_ATT64_ABLATE & 1, AB_BAR = CSM_ATT64_ABLATE & 2, AB_LDS = CSM_ATT64_ABLATE & 4, AB_MFMA = CSM_ATT64_ABLATE & 8,
+               AB_MAX = CSM_ATT64_ABLATE & 16;
+#define MFMA32_(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) (AB_MFMA ? (c) : MFMA32_(a, b, c))
 
 constexpr int TILE = 64 * 128;          // one 64-row x 64-column bf16 image
 constexpr int STAGE = 2 * TILE;         // K image + V image
@@ -35,7 +44,7 @@ constexpr int NSTAGE = 3;
 
 __device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fexp2(float x) { return AB_EXP ? x : __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -56,12 +65,14 @@ __device__ __forceinline__ float halves_sum(float x) {
 template <int OFF>
 __device__ __forceinline__ bf16x4 tr_read(unsigned addr) {
     bf16x4 v;
+    if (AB_LDS) { asm volatile("" : "=v"(v) : "v"(addr)); return v; }
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
     return v;
 }
 template <int OFF>
 __device__ __forceinline__ bf16x8 row_read(unsigned addr) {
     bf16x8 v;
+    if (AB_LDS) { asm volatile("" : "=v"(v) : "v"(addr)); return v; }
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
     return v;
 }
@@ -96,24 +107,41 @@ __device__ __forceinline__ void work_item(int nblk, int rep, int& pair, int& hh,
     blk = nblk - 1 - (local % nblk);
 }
 
-// one wave's 2 KiB share (pieces 2w, 2w+1) of a 64-row tile, by LDS-DMA
-__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ P, int ld, int S, int row0, char* img, int wave, int lane) {
+// one wave's 2 KiB share (pieces 2w, 2w+1) of a 64-row tile, by LDS-DMA.  The source address is a wave-uniform base
+// (tile start: scalar arithmetic) plus a per-lane byte offset computed ONCE (lane_off[i], see dma_lane_off), so a tile
+// costs no vector instructions besides the two loads; only a tile that overhangs the sequence end (rows clamped to
+// S - 1) recomputes its offsets.
+__device__ __forceinline__ void dma_lane_off(int ld, int wave, int lane, unsigned (&off)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int j = 2 * wave + i;
-        const int row = 8 * j + (lane >> 3);
-        int gr = row0 + row;
-        gr = gr < S ? gr : S - 1;
-        const int lc = (lane & 7) ^ swz(row);
-        const bf16_t* src = P + (size_t)gr * ld + lc * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(img + j * 1024), 16, 0, 0);
+        const int row = 8 * (2 * wave + i) + (lane >> 3);
+        off[i] = (unsigned)(row * ld + (((lane & 7) ^ swz(row)) << 3)) * 2u;
+    }
+}
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ P, int ld, int S, int row0, char* img, int wave, int lane,
+                                         const unsigned (&off)[2]) {
+    const char* base = reinterpret_cast<const char*>(P) + (size_t)row0 * ld * 2;      // wave-uniform
+    if (row0 + 64 <= S) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[i]),
+                                             (__attribute__((address_space(3))) void*)(img + (2 * wave + i) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * (2 * wave + i) + (lane >> 3);
+            int gr = row0 + row;
+            gr = gr < S ? gr : S - 1;
+            const bf16_t* src = P + (size_t)gr * ld + (((lane & 7) ^ swz(row)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(img + (2 * wave + i) * 1024), 16, 0, 0);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = 128 queries of one (b, h) = 4 waves x 32 queries; key blocks of 64
-__global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn64_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int S, int H, int KV, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int rep = H / KV;
@@ -144,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __rest
     {
         const int fx = swz(r);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ fx) << 4);
+        for (int ks = 0; ks < 4; ++ks) koff[ks] = sbase + r * 128 + (((2 * ks + h) ^ fx) << 4);
     }
     // V transposed fragments for (dt, u): k-rows 32t + 16s + 8u + 4(g>>1) + q, columns 32dt + 16(g&1) + 4p .. +3
     unsigned voff[2][2];
@@ -156,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __rest
             for (int u = 0; u < 2; ++u) {
                 const int row = 8 * u + 4 * (g >> 1) + q4;
                 const int ch = 4 * dt + 2 * (g & 1) + (p >> 1);
-                voff[dt][u] = TILE + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
+                voff[dt][u] = sbase + TILE + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
             }
     }
 
@@ -167,10 +195,11 @@ __global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __rest
     lastw = lastw < S ? lastw : S - 1;
     const int ntw = qw < S ? lastw / 32 + 1 : 0;        // key TILES (32 keys) this wave needs
 
-    auto stage_ptr = [&](int st) { return smem + st * STAGE; };
+    unsigned dma_off[2];
+    dma_lane_off(ld, wave, lane, dma_off);
     auto issue = [&](int kb, int st) {
-        dma_tile(Kp, ld, S, kb * 64, stage_ptr(st), wave, lane);
-        dma_tile(Vp, ld, S, kb * 64, stage_ptr(st) + TILE, wave, lane);
+        dma_tile(Kp, ld, S, kb * 64, smem + st * STAGE, wave, lane, dma_off);
+        dma_tile(Vp, ld, S, kb * 64, smem + st * STAGE + TILE, wave, lane, dma_off);
     };
 
     f32x16 o0, o1, lacc, zero16;
@@ -183,62 +212,68 @@ __global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __rest
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define EXP2(S_, I_) { S_[I_] = fexp2(fmaf(S_[I_], c2, nb)); S_[I_ + 1] = fexp2(fmaf(S_[I_ + 1], c2, nb)); }
-    // One 32-key tile of one wave.  c: S^T of this tile (computed one step earlier); n receives S^T of the next tile (NEXT),
-    // whose K rows sit at LDS address an.  Instruction order is pinned (sched_barrier between groups): an MFMA is followed
-    // by the exp2 of two scores (8 + 2 x 12 issue cycles per 32-cycle MFMA), so matrix pipe and VALU run together inside
-    // one wave instead of relying on the SIMD's other wave being in the opposite phase:
-    //   R1  4 MFMA  S^T(next tile)         |  exp2 of scores 0..7   (k-step 0 of the PV product)
+    // One 32-key tile (index t) of one wave, software-pipelined two tiles deep.  On entry: c = S^T of tile t, mnew = the
+    // running max including tile t, kf0..3 = K row fragments of tile t+1.  Instruction order is pinned (sched_barrier
+    // between groups): an MFMA is followed by the exp2 of two scores (8 + 2 x 12 issue cycles per 32-cycle MFMA), so
+    // matrix pipe and VALU run together inside one wave instead of relying on the SIMD's other waves:
+    //   R1  4 MFMA  S^T(t+1)               |  exp2 of scores 0..7 of tile t   (k-step 0 of the PV product)
+    //       K fragments of tile t+2 requested (they have all of R2 + R3 + the next R1's head to land)
     //   R2  3 MFMA  row sum + PV, k-step 0 |  exp2 of scores 8..15
-    //   R3  3 MFMA  row sum + PV, k-step 1
-    // TOFF = byte offset of the tile's 32 rows inside the K / V images (0 or 4096).
-    auto step = [&](auto next_tag, auto toff_tag, int key0, unsigned a, unsigned an, f32x16& c, f32x16& n) {
-        constexpr bool NEXT = decltype(next_tag)::value;
-        constexpr int TOFF = decltype(toff_tag)::value, NOFF = 4096 - TOFF;
-        bf16x8 k0, k1, k2, k3;
-        if (NEXT) { k0 = row_read<NOFF>(an + koff[0]); k1 = row_read<NOFF>(an + koff[1]); k2 = row_read<NOFF>(an + koff[2]); k3 = row_read<NOFF>(an + koff[3]); }
-        // V^T fragments: [k-step s][column half dt][row group u]
-        const bf16x4 v000 = tr_read<TOFF>(a + voff[0][0]), v001 = tr_read<TOFF>(a + voff[0][1]);
-        const bf16x4 v010 = tr_read<TOFF>(a + voff[1][0]), v011 = tr_read<TOFF>(a + voff[1][1]);
-        const bf16x4 v100 = tr_read<TOFF + 2048>(a + voff[0][0]), v101 = tr_read<TOFF + 2048>(a + voff[0][1]);
-        const bf16x4 v110 = tr_read<TOFF + 2048>(a + voff[1][0]), v111 = tr_read<TOFF + 2048>(a + voff[1][1]);
+    //   R3  3 MFMA  row sum + PV, k-step 1 |  causal mask (diagonal tiles only) and row max of S^T(t+1) -> mnew
+    // so nothing a tile needs first (its max, its K fragments) is computed or requested at its own head.
+    // A / AN / ANN = byte offsets of tiles t, t+1, t+2 inside the ring: compile-time (the block loop is unrolled over the
+    // three stages), so every LDS read is a lane-constant address register plus an immediate.
+    bf16x8 kf0, kf1, kf2, kf3;
+    float mnew = -INFINITY;
+    auto rowmax = [&](const f32x16& x) {
+        float x0 = vmax3(x[0], x[1], x[2]), x1 = vmax3(x[3], x[4], x[5]), x2 = vmax3(x[6], x[7], x[8]), x3 = vmax3(x[9], x[10], x[11]);
+        x0 = vmax3(x0, x[12], x[13]); x1 = vmax3(x1, x[14], x[15]);
+        x0 = vmax3(x0, x1, x2);
+        return vmax3(x0, x3, m);
+    };
+    auto causal = [&](f32x16& x, int key0) {
         if (key0 + 31 > qw) {                           // the tile crosses this wave's diagonal (wave-uniform)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (key0 + (i & 3) + 8 * (i >> 2) + 4 * h > qrow) c[i] = -INFINITY;
+                if (key0 + (i & 3) + 8 * (i >> 2) + 4 * h > qrow) x[i] = -INFINITY;
         }
-        float x0 = vmax3(c[0], c[1], c[2]), x1 = vmax3(c[3], c[4], c[5]), x2 = vmax3(c[6], c[7], c[8]), x3 = vmax3(c[9], c[10], c[11]);
-        x0 = vmax3(x0, c[12], c[13]); x1 = vmax3(x1, c[14], c[15]);
-        x0 = vmax3(x0, x1, x2);
-        const float m_new = halves_max(vmax3(x0, x3, m));
-        if (!__all(m_new == m)) {                       // rescale only when some query's running max moved
-            const float alpha = fexp2((m - m_new) * c2);
+    };
+    auto step = [&](auto a_tag, auto an_tag, auto ann_tag, int key0, f32x16& c, f32x16& n) {
+        constexpr int A = decltype(a_tag)::value, AN = decltype(an_tag)::value, ANN = decltype(ann_tag)::value;
+        // V^T fragments: [k-step s][column half dt][row group u]
+        const bf16x4 v000 = tr_read<A>(voff[0][0]), v001 = tr_read<A>(voff[0][1]);
+        const bf16x4 v010 = tr_read<A>(voff[1][0]), v011 = tr_read<A>(voff[1][1]);
+        const bf16x4 v100 = tr_read<A + 2048>(voff[0][0]), v101 = tr_read<A + 2048>(voff[0][1]);
+        const bf16x4 v110 = tr_read<A + 2048>(voff[1][0]), v111 = tr_read<A + 2048>(voff[1][1]);
+        if (!AB_MAX && !__all(mnew == m)) {             // rescale only when some query's running max moved
+            const float alpha = fexp2((m - mnew) * c2);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
             lacc[0] *= alpha;                           // every row of lacc is the same sum; only row 0 is read
-            m = m_new;
+            m = mnew;
         }
         const float nb = -m * c2;
         // ---- R1
-        if (NEXT) {
-            LGKM_WAIT(8);                                // the K fragments have landed (the 8 V reads may still fly)
-            n = MFMA32(k0, qf[0], zero16); SB(); EXP2(c, 0) SB();
-            n = MFMA32(k1, qf[1], n); SB(); EXP2(c, 2) SB();
-            n = MFMA32(k2, qf[2], n); SB(); EXP2(c, 4) SB();
-            n = MFMA32(k3, qf[3], n); SB(); EXP2(c, 6) SB();
-        } else {
-            EXP2(c, 0) EXP2(c, 2) EXP2(c, 4) EXP2(c, 6)
-        }
+        LGKM_WAIT(8);                                    // the K fragments (requested one step ago) have landed
+        n = MFMA32(kf0, qf[0], zero16); SB(); EXP2(c, 0) SB();
+        n = MFMA32(kf1, qf[1], n); SB(); EXP2(c, 2) SB();
+        n = MFMA32(kf2, qf[2], n); SB(); EXP2(c, 4) SB();
+        n = MFMA32(kf3, qf[3], n); SB(); EXP2(c, 6) SB();
         const bf16x8 p0 = pack8f(c, 0);
-        LGKM_WAIT(0);
+        LGKM_WAIT(0);                                    // this tile's V fragments
+        kf0 = row_read<ANN>(koff[0]); kf1 = row_read<ANN>(koff[1]); kf2 = row_read<ANN>(koff[2]); kf3 = row_read<ANN>(koff[3]);
         // ---- R2
         lacc = MFMA32(ones, p0, lacc); SB(); EXP2(c, 8) SB();
         o0 = MFMA32(cat4(v000, v001), p0, o0); SB(); EXP2(c, 10) SB();
         o1 = MFMA32(cat4(v010, v011), p0, o1); SB(); EXP2(c, 12) EXP2(c, 14) SB();
         const bf16x8 p1 = pack8f(c, 1);
         // ---- R3
-        lacc = MFMA32(ones, p1, lacc);
-        o0 = MFMA32(cat4(v100, v101), p1, o0);
-        o1 = MFMA32(cat4(v110, v111), p1, o1);
+        lacc = MFMA32(ones, p1, lacc); SB();
+        causal(n, key0 + 32);
+        o0 = MFMA32(cat4(v100, v101), p1, o0); SB();
+        const float mx = rowmax(n); SB();
+        o1 = MFMA32(cat4(v110, v111), p1, o1); SB();
+        mnew = AB_MAX ? m : halves_max(mx);
     };
 #undef EXP2
 
@@ -246,31 +281,41 @@ __global__ __launch_bounds__(256, 2) void attn64_fwd_kernel(const bf16_t* __rest
     if (nkb > 1) { issue(1, 1); VM_WAIT(4); } else { VM_WAIT(0); }
     __builtin_amdgcn_s_barrier();
 
-    using T1 = std::integral_constant<bool, true>;
-    using T0 = std::integral_constant<bool, false>;
-    using OFF0 = std::integral_constant<int, 0>;
-    using OFF1 = std::integral_constant<int, 4096>;
+    // tile positions inside the ring: stage s, tile 0 / 1
+    using P00 = std::integral_constant<int, 0>;
+    using P01 = std::integral_constant<int, 4096>;
+    using P10 = std::integral_constant<int, STAGE>;
+    using P11 = std::integral_constant<int, STAGE + 4096>;
+    using P20 = std::integral_constant<int, 2 * STAGE>;
+    using P21 = std::integral_constant<int, 2 * STAGE + 4096>;
     f32x16 sa, sb;
-    if (ntw > 0) {                                       // S^T of tile 0
-        bf16x8 k0 = row_read<0>(sbase + koff[0]), k1 = row_read<0>(sbase + koff[1]), k2 = row_read<0>(sbase + koff[2]), k3 = row_read<0>(sbase + koff[3]);
-        LGKM_WAIT(0);
+    if (ntw > 0) {                                       // S^T and row max of tile 0, K fragments of tile 1
+        bf16x8 k0 = row_read<0>(koff[0]), k1 = row_read<0>(koff[1]), k2 = row_read<0>(koff[2]), k3 = row_read<0>(koff[3]);
+        kf0 = row_read<4096>(koff[0]); kf1 = row_read<4096>(koff[1]); kf2 = row_read<4096>(koff[2]); kf3 = row_read<4096>(koff[3]);
+        LGKM_WAIT(4);
         sa = MFMA32(k0, qf[0], zero16); sa = MFMA32(k1, qf[1], sa); sa = MFMA32(k2, qf[2], sa); sa = MFMA32(k3, qf[3], sa);
+        causal(sa, 0);
+        mnew = halves_max(rowmax(sa));
     }
-    int st = 0;                                          // stage of block kb
-    for (int kb = 0; kb < nkb; ++kb) {
-        VM_WAIT(0);                                      // block kb+1 (issued one iteration ago) has landed
-        __builtin_amdgcn_s_barrier();                    // ... for every wave; and stage (kb+2)%3 is no longer read
-        const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-        if (kb + 2 < nkb) issue(kb + 2, st2);
-        const unsigned a = sbase + st * STAGE, an = sbase + st1 * STAGE;
-        // tile 2kb (set a; next = tile 2kb+1 of the same block -> set b)
-        // (S^T of the following tile is computed even when the wave will not use it - at most one wasted tile per wave -
-        // so that the loop body has a single code path: two versions of a step merge ~100 live registers through copies)
-        if (2 * kb < ntw) step(T1{}, OFF0{}, kb * 64, a, a, sa, sb);
-        // tile 2kb+1 (set b; next = tile 0 of block kb+1 -> set a)
-        if (2 * kb + 1 < ntw) step(T1{}, OFF1{}, kb * 64 + 32, a, an, sb, sa);
-        st = st1;
+    // One key block: wait for block kb+1 (issued one block ago), barrier, issue block kb+2 into the stage the barrier has
+    // just released, then the block's two tiles.  A step also computes S^T of tile t+1 and requests K of tile t+2 when the
+    // wave will not use them (garbage from a stage that holds some other block, never consumed), so that a step has a
+    // single code path: two versions of it would merge ~100 live registers through copies.
+#define BLOCK(KB, C0, C1, N0, N1, NNIDX)                                                                               \
+    {                                                                                                                  \
+        if (!AB_BAR) { VM_WAIT(0); __builtin_amdgcn_s_barrier(); }                                                     \
+        if (!AB_BAR && (KB) + 2 < nkb) issue((KB) + 2, NNIDX);                                                         \
+        if (2 * (KB) < ntw) step(C0{}, C1{}, N0{}, (KB) * 64, sa, sb);                                                 \
+        if (2 * (KB) + 1 < ntw) step(C1{}, N0{}, N1{}, (KB) * 64 + 32, sb, sa);                                        \
     }
+    for (int kb = 0; kb < nkb; kb += 3) {
+        BLOCK(kb, P00, P01, P10, P11, 2)
+        if (kb + 1 >= nkb) break;
+        BLOCK(kb + 1, P10, P11, P20, P21, 0)
+        if (kb + 2 >= nkb) break;
+        BLOCK(kb + 2, P20, P21, P00, P01, 1)
+    }
+#undef BLOCK
 #undef SB
 
     // ---- epilogue: O^T registers -> LDS [q][d] (144-B rows) -> whole 128-B rows to HBM
