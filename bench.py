@@ -40,7 +40,9 @@ def parse():
                     help="A: semantic CE only (reference loss); B: + decoder on all frames; C: + decoder on 1/16 of frames")
     ap.add_argument("--lora", action="store_true", help="configs[2]: LoRA r=8 q_proj/v_proj instead of full-param")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seq", type=int, default=256, help="positions of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seq", type=int, default=2048, help="positions of the CPU-baseline sample (SURVEY 8d protocol: B=1, S=2048)")
+    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (loss modes A / B, LoRA B=8, generate 10 s)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only; the number is not the metric)")
     return ap.parse_args()
 
@@ -129,37 +131,86 @@ class GemmTimer:
 
 def pmc_traffic(kind):
     """HBM-side bytes per launch of a GEMM kind from the committed rocprofv3 PMC passes over this same command
-    (profiles/run_pmc_bench_r01.sh -> profiles/r01_bench_pmc_traffic.json); None when the file is not there.  Counters
+    (profiles/run_pmc_bench_rNN.sh -> the newest profiles/rNN_bench_pmc_traffic.json); None when there is none.  Counters
     cannot be read from inside the timed process, so this is the profile's figure, not a live one."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
-    if not os.path.exists(path):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
+    if not files:
         return None, None
-    t = json.load(open(path)).get(kind)
+    t = json.load(open(files[-1])).get(kind)
     if not t:
         return None, None
-    return t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"], "profiles/r01_bench_pmc_traffic.json"
+    return t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(model, cfg_fn, seq, seed, sw, aw):
-    """The oracle (CPU restatement of the reference PyTorch path) on this box's host cores: one full-param fp32 train
-    step (loss -> backward -> clip -> AdamW), semantic loss only (what the reference computes), B=1, S=seq.
+def attention_flops(args_model, B, S, n_dec_frames):
+    """Algorithmic attention FLOPs of one train step (causal half; forward + 2.5x backward)."""
+    bb, dc = args_model.bb, args_model.dc
+    one = lambda c, b, s: 4.0 * b * c.num_heads * (s * s / 2.0) * c.head_dim * c.num_layers   # noqa: E731
+    return 3.5 * (one(bb, B, S) + (one(dc, n_dec_frames, args_model.args.audio_num_codebooks) if n_dec_frames else 0.0))
+
+
+def cpu_baseline(model, cfg_fn, seq, seed, sw, aw, budget_s):
+    """The oracle (CPU restatement of the reference PyTorch path) on this box's host cores, SURVEY 8d / reference
+    src/csm/training/benchmark_lora.py:536-571 protocol: full-param fp32 train step (loss -> backward -> clip -> AdamW,
+    semantic loss only = what the reference computes), B=1, S=seq, one fixed synthetic batch, 1 warm-up step + timed
+    steps on all cores, plus a 1-thread figure.  Bounded: a step at S=2048 is tens of seconds of CPU work, so the number of
+    timed steps (1..3) and the size of the 1-thread sample follow from the measured warm-up step and ``budget_s``.
     Uses the SAME weights as the GPU model (its bf16 values widened to fp32), so the two losses are comparable."""
     from oracle import csm_oracle as O
     cfg = cfg_fn()
     params = {k: v.float().cpu().requires_grad_(True) for k, v in model._views(model.arena).items()}
+    plist = list(params.values())
     tokens, mask, targets = O.synthetic_batch(cfg, 1, seq, seed=seed)
     threads = torch.get_num_threads()
-    t0 = time.time()
-    total, det = O.compute_loss(params, cfg, tokens, mask, targets, sw, aw, acoustic_rows="off")
-    total.backward()
-    plist = list(params.values())
     opt = torch.optim.AdamW(plist, lr=1e-5, weight_decay=0.01)
-    torch.nn.utils.clip_grad_norm_(plist, 1.0)
-    opt.step()
-    dt = time.time() - t0
+
+    def step(tk, mk, tg):
+        t0 = time.time()
+        opt.zero_grad(set_to_none=True)
+        total, _ = O.compute_loss(params, cfg, tk, mk, tg, sw, aw, acoustic_rows="off")
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(plist, 1.0)
+        opt.step()
+        return time.time() - t0, float(total.detach())
+
+    t_warm, loss0 = step(tokens, mask, targets)            # warm-up (allocates the AdamW state); its loss is the parity value
+    timed = []
+    left = budget_s - t_warm
+    reserve = 30.0                                         # kept for the 1-thread sample once one timed step exists
+    while len(timed) < 3 and left > 1.3 * (min(timed) if timed else t_warm) + (reserve if timed else 0.0):
+        dt, _ = step(tokens, mask, targets)
+        timed.append(dt)
+        left -= dt
+    note = ""
+    if not timed:                                          # the budget does not even hold one timed step: report the cold one
+        timed, note = [t_warm], " (budget exhausted by the warm-up step: this is the COLD step)"
+    dt = sum(timed) / len(timed)
+    # 1-thread figure on a short sample (a 1-thread step at S=2048 would take the better part of an hour)
+    one = None
+    if left > 20:
+        s1 = max(16, min(seq, 64))
+        tk1, mk1, tg1 = O.synthetic_batch(cfg, 1, s1, seed=seed + 1)
+        torch.set_num_threads(1)
+        try:
+            d1, _ = step(tk1, mk1, tg1)
+        finally:
+            torch.set_num_threads(threads)
+        one = {"value": s1 / d1, "unit": "tokens/s", "cores": 1, "sample": f"1 step at B=1,S={s1}, {d1:.1f}s (optimiser pass over 1.55 B "
+               "fp32 parameters included, which dominates a sample this short)"}
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return dict(value=seq / dt, unit="tokens/s", cores=threads, kind="port",
-                sample=f"1 full-param fp32 train step (oracle: fwd+bwd+clip+AdamW, semantic loss) at B=1,S={seq}, {dt:.1f}s",
-                loss=float(total)), (tokens, mask, targets)
+                sample=f"full-param fp32 train step of the oracle (fwd+bwd+clip+AdamW, semantic loss = the reference's compute_loss) at "
+                       f"B=1,S={seq}: 1 warm-up step ({t_warm:.1f}s) + {len(timed)} timed step(s), mean {dt:.1f}s{note}",
+                os_cpu_count=os.cpu_count(), torch_threads=threads, cpu_model=cpu_model, one_thread=one,
+                loss=loss0), (tokens, mask, targets)
 
 
 def main():
@@ -197,62 +248,103 @@ def main():
         a.seq = min(a.seq, 128)
     else:
         args = csm_1b_args()
-    model = Model(args, device=f"cuda:{local}", seed=0)          # random init, same on every rank
-    model.acoustic_mode = {"A": "off", "B": "all", "C": "amortized"}[a.mode]
     import tempfile
-    tr = CSMTrainer("", tempfile.mkdtemp(prefix=f"csm_bench_rank{rank}_"), device=f"cuda:{local}")   # trainer wants an output dir
-    tr.logger.setLevel(30)
-    tr.model = model
-    if a.lora:
-        apply_lora_to_model(model, r=8, alpha=16.0, target_modules=["q_proj", "v_proj"])
-        tr.optimizer = FusedAdamW(model, {}, lora_lr=1e-4)
-        tr.grad_sync = GradSync.for_model(model) if GradSync.active() else None
-    else:
-        tr.prepare_optimizer()
 
-    ds = SyntheticCSMDataset(a.batch, a.seq, args.text_vocab_size, args.audio_vocab_size, args.audio_num_codebooks,
-                             seed=1234 + rank)
-    batch = {k: v.cuda() for k, v in collate_variable_length([ds[i] for i in range(a.batch)]).items()}
+    def make_trainer(model, lora):
+        tr = CSMTrainer("", tempfile.mkdtemp(prefix=f"csm_bench_rank{rank}_"), device=f"cuda:{local}")   # trainer wants an output dir
+        tr.logger.setLevel(30)
+        tr.model = model
+        if lora:
+            apply_lora_to_model(model, r=8, alpha=16.0, target_modules=["q_proj", "v_proj"])
+            if GradSync.active():
+                GradSync.broadcast_parameters(model)
+            tr.optimizer = FusedAdamW(model, {}, lora_lr=1e-4)
+            tr.grad_sync = GradSync.for_model(model) if GradSync.active() else None
+        else:
+            tr.prepare_optimizer()
+        return tr
+
+    def make_batch(nb):
+        ds = SyntheticCSMDataset(nb, a.seq, args.text_vocab_size, args.audio_vocab_size, args.audio_num_codebooks, seed=1234 + rank)
+        return {k: v.cuda() for k, v in collate_variable_length([ds[i] for i in range(nb)]).items()}
 
     K_ = args.audio_num_codebooks
+
+    def run(tr, batch, warmup, steps, with_timer=True):
+        """W untimed + K timed optimiser steps, barrier + device sync on both sides, MAX over ranks.  Returns a dict."""
+        for _ in range(warmup):
+            tr.train_step(batch, 1, True, 1.0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gt = None
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # per-step spread (no host sync inside the loop)
+        marks[0].record()
+        for i in range(steps):
+            if with_timer and i == steps - 1:
+                with GemmTimer() as gt:
+                    loss, det = tr.train_step(batch, 1, True, 1.0)
+            else:
+                loss, det = tr.train_step(batch, 1, True, 1.0)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        nb = batch["input_tokens"].shape[0]
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(max(1, steps - 1))) or [dt / steps * 1e3]
+        return dict(dt=dt, steps=steps, ms=dt / steps * 1e3, tokens_per_s=world * nb * a.seq / (dt / steps), gt=gt, loss=float(loss),
+                    per_step=per_step, nb=nb)
+
+    def step_flops(model, res):
+        """GEMM FLOPs of the instrumented step + algorithmic attention FLOPs (causal half, 3.5x forward for fwd+bwd)."""
+        kinds = res["gt"].summary() if res["gt"] is not None else {}
+        n_dec = 0
+        if model.acoustic_mode != "off":
+            nfr = res["nb"] * (a.seq - 1)
+            n_dec = nfr if model.acoustic_mode == "all" else max(1, int(round(nfr * model.acoustic_fraction)))
+        gemm = sum(v["flop"] for v in kinds.values())
+        return kinds, gemm, attention_flops(model, res["nb"], a.seq, n_dec)
+
+    def leg_summary(model, res, what):
+        kinds, gemm, att = step_flops(model, res)
+        tf = (gemm + att) / (res["ms"] * 1e-3) / 1e12
+        return {"workload": what, "ms_per_step": round(res["ms"], 3), "tokens_per_s": round(res["tokens_per_s"], 1), "steps": res["steps"],
+                "loss": res["loss"],
+                "roofline": {"bound": "mfma", "what": "whole step: GEMM + attention FLOP / step time", "achieved": round(tf, 1),
+                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}}
+
+    model = Model(args, device=f"cuda:{local}", seed=0)          # random init, same on every rank (and broadcast from rank 0)
+    model.acoustic_mode = {"A": "off", "B": "all", "C": "amortized"}[a.mode]
+    tr = make_trainer(model, a.lora)
+    if tr.grad_sync is not None:
+        tr.grad_sync.timing = True
+    batch = make_batch(a.batch)
     cb_tokens = int(batch["input_masks"][:, :, 0].sum()) * K_ + int(batch["input_masks"][:, :, K_].sum())
+    res = run(tr, batch, a.warmup, a.steps)
+    dt, ms, tokens_per_s, gt, loss = res["dt"], res["ms"], res["tokens_per_s"], res["gt"], res["loss"]
+    exposed = tr.grad_sync.exposed_comm_ms()[-a.steps:] if tr.grad_sync is not None else None
 
-    def step():
-        return tr.train_step(batch, 1, True, 1.0)
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gt = None
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step spread (no host sync inside the loop)
-    marks[0].record()
-    for i in range(a.steps):
-        if i == a.steps - 1:
-            with GemmTimer() as gt:
-                loss, det = step()
-        else:
-            loss, det = step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
-    ms = dt / a.steps * 1e3
-    tokens_per_s = world * a.batch * a.seq / (dt / a.steps)
+    # ---- N > 1: BASELINE config 4 proper is 8 sequences per GPU (global batch 64 on 8 GPUs).  The headline keeps 4 per GPU
+    # at every N so that the driver's scaling curve compares equal per-GPU work; config 4's own number is reported beside it.
+    dp_b8 = None
+    if world > 1 and not a.tiny and not a.lora and a.batch != 8:
+        r8 = run(tr, make_batch(8), 2, 5, with_timer=False)
+        dp_b8 = {"workload": f"BASELINE config 4: full-param bf16 DP, seq={a.seq}, 8 sequences/GPU, global batch {8 * world}",
+                 "ms_per_step": round(r8["ms"], 3), "tokens_per_s": round(r8["tokens_per_s"], 1), "steps": r8["steps"],
+                 "exposed_comm_ms": round(sum(tr.grad_sync.exposed_comm_ms()[-5:]) / 5, 3)}
 
     if rank == 0:
-        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps - 1)) or [ms]   # last step carries the GEMM timers
+        per_step = res["per_step"]
         pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)   # noqa: E731
-        kinds = gt.summary() if gt is not None else {}
+        kinds, gemm_flop, att_flop = step_flops(model, res)
         bf = {k: v for k, v in kinds.items() if k.endswith("_bf16")}
         dom = max(bf.items(), key=lambda kv: kv[1]["time_ms"]) if bf else (None, None)
         roof = None
@@ -262,8 +354,9 @@ def main():
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                     "operand_bytes_per_launch": round(dom[1]["operand_bytes_per_launch"]),
-                    "peak_note": "dense bf16 MFMA peak of the micro-architecture guide; the chip is power limited on non-zero data: a "
-                                 "register-only MFMA loop reaches 1.56-1.85 PFLOP/s on random bf16 operands (tools/probes/mfma_shape_probe.hip)",
+                    "peak_note": "dense bf16 MFMA peak of the micro-architecture guide (2.4 GHz); the chip is power limited on non-zero data: a "
+                                 "register-only MFMA loop reaches 1.56-1.85 PFLOP/s on random bf16 operands (tools/probes/mfma_shape_probe.hip, "
+                                 "profiles/r02_clock_power.txt)",
                     "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
                     "all_gemm_variants": {k: {"tflops": round(v["tflops"], 1), "ms_per_step": round(v["time_ms"], 2),
                                               "launches": v["launches"]} for k, v in kinds.items()}}
@@ -273,17 +366,62 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("tiny-plumbing" if a.tiny else "CSM-1B") + (" LoRA r=8 q_proj/v_proj" if a.lora else " full-param")
                        + f" bf16 train step, seq={a.seq}, batch={a.batch}/GPU, loss mode {a.mode}"
-                       + (" (semantic CE + depth decoder on 1/16 of frames)" if a.mode == "C" else ""),
+                       + (" (semantic CE + depth decoder on 1/16 of frames)" if a.mode == "C" else "")
+                       + (f"; weak scaling keeps {a.batch} sequences/GPU at every N - BASELINE config 4's 8/GPU is in extra.dp_config4_b8" if world > 1 else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq, "parallelism": f"dp{world}"},
             "codebook_tokens_per_s": round(world * cb_tokens / (dt / a.steps), 1),   # secondary: 32 per audio frame + 1 per text token
-            "mfma_utilisation_step": round(sum(v["flop"] for v in kinds.values()) / (dt / a.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
-            if kinds else None,                                # GEMM FLOP of one step / step time / dense peak (attention not counted)
+            # GEMM FLOP + algorithmic attention FLOP (causal half, backward = 2.5x forward) of one step / step time / dense peak
+            "mfma_utilisation_step": round((gemm_flop + att_flop) / (dt / a.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if kinds else None,
+            "step_flop": {"gemm": gemm_flop, "attention": att_flop},
             "hbm_kernel": gt.adamw_summary() if gt is not None else None,
             "loss": float(loss), "step_ms": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}, "roofline": roof,
         }
+        if exposed is not None:
+            out["exposed_comm_ms"] = {"mean": round(sum(exposed) / len(exposed), 3), "max": round(max(exposed), 3),
+                                      "what": "per step: time the compute stream waits for the gradient collectives after the backward"}
+    extra = {}
+    if dp_b8 is not None:
+        extra["dp_config4_b8"] = dp_b8
+
+    # ---- extra legs (1 GPU only, outside the headline's timed region): the other loss modes of SURVEY 8d, BASELINE
+    # configs 3 (LoRA r=8 q/v, B=8) and 5 (generate 10 s of audio)
+    if world == 1 and not a.no_extras and not a.tiny and not a.lora and a.mode == "C":
+        for mode, (w, k) in (("A", (3, 10)), ("B", (1, 3))):
+            model.acoustic_mode = {"A": "off", "B": "all"}[mode]
+            r = run(tr, batch, w, k)
+            extra[f"mode_{mode}"] = leg_summary(model, r, f"full-param, batch {a.batch}, loss mode {mode} ("
+                                                + ("semantic CE only = the reference's compute_loss" if mode == "A" else "depth decoder on every frame") + ")")
+        model.acoustic_mode = "amortized"
+        # free the full-param trainer before the LoRA model is built
+        del tr, res, gt
+        lm = Model(args, device=f"cuda:{local}", seed=0)
+        lm.acoustic_mode = "amortized"
+        ltr = make_trainer(lm, True)
+        r = run(ltr, make_batch(8), 3, 10)
+        extra["lora_b8"] = leg_summary(lm, r, f"BASELINE config 3: LoRA r=8 q_proj/v_proj, seq={a.seq}, batch 8, loss mode C")
+        del ltr, lm, r
+        torch.cuda.empty_cache()
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import generate_bench
+            g = generate_bench.run(model, frames=125)
+            bytes_frame = 9.1e9                                       # weights streamed per 80 ms frame, batch 1
+            extra["generate_10s"] = {"workload": "BASELINE config 5: Mimi encode of 5 s context + 125 AR frames (32 codebooks) + Mimi decode",
+                                     **g,
+                                     "roofline": {"bound": "hbm", "achieved": round(bytes_frame / (g["ms_per_frame"] * 1e-3) / 1e9, 1),
+                                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                  "frac": round(bytes_frame / (g["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                  "bytes_per_frame": bytes_frame}}
+        except Exception as e:  # noqa: BLE001 - an extra leg must never take the headline line down
+            extra["generate_10s"] = {"error": repr(e)}
+
+    if rank == 0:
+        if extra:
+            out["extra"] = extra
         if not a.no_cpu_baseline and world == 1:
             from oracle import csm_oracle as O
-            cb, (ct, cm, cg) = cpu_baseline(model, (O.tiny_cfg if a.tiny else O.csm_1b_cfg), min(a.cpu_seq, a.seq), 4321, 100.0, 1.0)
+            cb, (ct, cm, cg) = cpu_baseline(model, (O.tiny_cfg if a.tiny else O.csm_1b_cfg), min(a.cpu_seq, a.seq), 4321, 100.0, 1.0,
+                                            a.cpu_budget)
             mode = model.acoustic_mode
             model.acoustic_mode = "off"
             with torch.no_grad():
@@ -291,7 +429,7 @@ def main():
             model.acoustic_mode = mode
             cpu_loss = cb.pop("loss")
             out["cpu_baseline"] = cb
-            out["parity_check"] = {"what": "loss of the same weights/batch: HIP bf16 path vs CPU fp32 oracle", "cpu_loss": cpu_loss,
+            out["parity_check"] = {"what": f"loss of the same weights/batch (B=1, S={ct.shape[1]}): HIP bf16 path vs CPU fp32 oracle", "cpu_loss": cpu_loss,
                                    "gpu_loss": float(gl), "rel_diff": abs(float(gl) - cpu_loss) / abs(cpu_loss)}
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:

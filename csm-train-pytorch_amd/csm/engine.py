@@ -79,6 +79,19 @@ class _Stack:
             ad1, ad3 = self._lora(i, "w1"), self._lora(i, "w3")
             if FUSE_SWIGLU and ad1 is None and ad3 is None:
                 ops.linear_swiglu_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu, act)   # activation fused into the GEMM epilogue
+            elif FUSE_SWIGLU and not any(ad is not None and ad.bias is not None for ad in (ad1, ad3)):
+                # LoRA on w1 / w3 without leaving the fused path: the adapters' (alpha/r) t B^T is written FIRST, for both
+                # at once - t13 = [t1 | t3], B13 = B1 / B3 rows interleaved like w13 (block diagonal) - and the frozen
+                # product takes it in through the residual port of its SwiGLU epilogue: gate/up = acc + R, act from the sum
+                rp = (ad1 or ad3).r
+                t13 = torch.zeros(M, 2 * rp, dtype=BF16, device=dev)
+                B13 = torch.zeros(2 * F, 2 * rp, dtype=BF16, device=dev)
+                for mod, col, ad in (("w1", 0, ad1), ("w3", 1, ad3)):
+                    if ad is not None:
+                        a[f"t_{mod}"] = ad.project(hn, t13[:, col * rp:(col + 1) * rp])
+                        B13[col::2, col * rp:(col + 1) * rp] = ad.B
+                ops.gemm(t13, B13, gu, None, alpha=(ad1 or ad3).scaling)
+                ops.linear_swiglu_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu, act, residual=gu)
             else:
                 ops.linear_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu)
                 if ad1 is not None or ad3 is not None:
@@ -210,15 +223,7 @@ class Engine:
         tk = tokens.reshape(M, K1).to(device=dev, dtype=torch.int64).contiguous()
         mk = masks.reshape(M, K1).to(device=dev, dtype=torch.uint8).contiguous()
         ign = getattr(m, "target_ignore_index", None)     # None: reference behaviour, every row counts (utils.py:102-105)
-        # range check where the tensor lives (a DataLoader batch is still on the host: no device sync), once per tensor
-        # version - a batch that is fed again (benchmarks, gradient accumulation over one batch) is not re-validated
-        vkey = (targets.data_ptr(), targets._version, tuple(targets.shape), ign)
-        if vkey != getattr(self, "_validated_targets", None):
-            if int(targets.max()) >= V or (ign is None and int(targets.min()) < 0):
-                raise ValueError("target_audio_tokens out of range for audio_vocab_size")
-            if ign is not None and bool(((targets < 0) & (targets != ign)).any()):
-                raise ValueError(f"negative target_audio_tokens other than the ignore index {ign}")
-            self._validated_targets = vkey
+        self._validate_batch(tokens, masks, targets, ign)
         tg = targets.to(device=dev, dtype=torch.int64)
 
         h0 = torch.empty(M, d, dtype=BF16, device=dev)
@@ -249,6 +254,36 @@ class Engine:
             self.saved = dict(B=B, S=S, tk=tk, mk=mk, hidden=hidden, logits=logits, t0=t0, n_sem=n_sem, dec=dec,
                               sw=float(semantic_weight), aw=float(acoustic_weight))
         return total[0], sem[0], ac[0]
+
+    def _validate_batch(self, tokens, masks, targets, ign):
+        """Range checks of the integer inputs: the kernels index embedding tables, logits rows and gradient tables with
+        them unchecked, so an id outside its table is an out-of-bounds device access (the reference's nn.Embedding /
+        F.cross_entropy would assert).  Host batches (what a DataLoader hands over) are checked every time - min / max of
+        a few hundred thousand integers on the CPU, no device sync.  Device-resident batches (benchmarks, gradient
+        accumulation over one batch) cost a device sync, so a verdict is remembered for that exact tensor version."""
+        a = self.m.args
+        V, TV, K = a.audio_vocab_size, a.text_vocab_size, a.audio_num_codebooks
+
+        def check(tk, mk, tg):
+            if int(tg.max()) >= V or (ign is None and int(tg.min()) < 0):
+                raise ValueError("target_audio_tokens out of range for audio_vocab_size")
+            if ign is not None and bool(((tg < 0) & (tg != ign)).any()):
+                raise ValueError(f"negative target_audio_tokens other than the ignore index {ign}")
+            live = mk.bool()
+            au, tx = tk[..., :K], tk[..., K]
+            au_live, tx_live = au[live[..., :K]], tx[live[..., K]]
+            if au_live.numel() and (int(au_live.min()) < 0 or int(au_live.max()) >= V):
+                raise ValueError("input_tokens: audio code out of range for audio_vocab_size")
+            if tx_live.numel() and (int(tx_live.min()) < 0 or int(tx_live.max()) >= TV):
+                raise ValueError("input_tokens: text id out of range for text_vocab_size")
+
+        if not (tokens.is_cuda or targets.is_cuda):
+            check(tokens, masks, targets)
+            return
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (tokens, masks, targets)) + (ign,)
+        if key != getattr(self, "_validated_batch", None):
+            check(tokens, masks, targets)
+            self._validated_batch = key
 
     def _acoustic_rows(self, B, S, rows, t0=None):
         """Flattened (b*S + p) indices, p < S-1, of the positions whose frame trains the depth decoder.  ``t0`` (the
@@ -444,15 +479,20 @@ class Engine:
         Bn, Sn, K1 = tokens.shape
         first = int(input_pos[0, 0]) == 0
         st = getattr(m, "_decode_state", None)
-        if first or st is None or st.B != Bn:
+        if not first and (st is None or st.B != Bn or st.cur < 0):
+            raise RuntimeError("generate_frame: a non-first call (input_pos > 0) needs the state of a prompt prefilled with the "
+                               "same batch size (call it with input_pos starting at 0 first)")
+        if first:
             st = m._decode_state = DecodeState(self, Bn)
         if first:
             last_h = st.prefill(tokens, tokens_mask)
             return self._frame_tail(st, last_h, temperature, topk, noise)
         if Sn != 1:
             raise ValueError("generate_frame with caches: after the prompt, feed one position per call")
-        if noise is None and getattr(m, "use_hip_graph", True):
-            return st.graph_frame(tokens, tokens_mask, temperature, topk)
+        if getattr(m, "use_hip_graph", True):
+            return st.graph_frame(tokens, tokens_mask, temperature, topk, noise)
+        if st.cur + 1 >= m.bb.max_seq_len:          # the decode kernels index LDS and the KV caches with the position
+            raise ValueError("sequence exceeds max_seq_len")
         st.cur += 1
         return self._decode_frame(st, tokens, tokens_mask, temperature, topk, noise)
 
@@ -467,23 +507,29 @@ class Engine:
         return self._frame_tail(st, last_h, temperature, topk, noise)
 
     def _decode_frame(self, st, tokens, tokens_mask, temperature, topk, noise):
-        """One decode frame with no host-side dependence on device data: this is the body a HIP graph captures."""
+        """One decode frame, eagerly."""
+        st.fill_noise(noise)
+        return self._decode_frame_body(st, tokens, tokens_mask, temperature, topk)
+
+    def _decode_frame_body(self, st, tokens, tokens_mask, temperature, topk):
+        """One decode frame with no host-side dependence on device data and no random draw: this is the body a HIP graph
+        captures (the frame's Exp(1) noise sits in ``st.noise_buf``, filled before the body runs / the graph replays)."""
         last_h = st.backbone_step(tokens, tokens_mask)
-        return self._frame_tail(st, last_h, temperature, topk, noise)
+        return self._frame_tail_body(st, last_h, temperature, topk)
 
     def _frame_tail(self, st, last_h, temperature, topk, noise):
+        st.fill_noise(noise)
+        return self._frame_tail_body(st, last_h, temperature, topk)
+
+    def _frame_tail_body(self, st, last_h, temperature, topk):
         m, a = self.m, self.m.args
-        dev = m.device
         K, V = a.audio_num_codebooks, a.audio_vocab_size
         from .models.model import sample_topk
 
-        # all Exp(1) draws of the frame in one launch (the reference draws them one codebook at a time, model.py:79-82)
-        B = last_h.shape[0]
-        qall = None if noise is not None else torch.empty(K, B, V, dtype=F32, device=dev).exponential_(1)
+        qall = st.noise_buf          # all Exp(1) draws of the frame (the reference draws them one codebook at a time, model.py:79-82)
 
         def draw(lg, i):
-            q = qall[i] if noise is None else noise[i].to(dev)
-            return sample_topk(lg[:, :V], topk, temperature, q)
+            return sample_topk(lg[:, :V], topk, temperature, qall[i])
 
         ops.gemv(last_h, m.block("codebook0_head.padded"), st.logits)
         samples = [draw(st.logits, 0)]
@@ -619,9 +665,20 @@ class DecodeState:
         self.dpos = [torch.full((B,), i, dtype=torch.int32, device=dev) for i in range(m.args.audio_num_codebooks)]
         self.cur = -1
         self.graph, self.graph_key, self.warm = None, None, 0
+        # the frame's Exp(1) draws [K, B, V]: a PERSISTENT buffer, refilled before every frame outside the captured graph -
+        # so a replayed frame can be given the same noise as an eager one (parity tests) or fresh draws (generation)
+        self.noise_buf = torch.empty(m.args.audio_num_codebooks, B, m.args.audio_vocab_size, dtype=F32, device=dev)
         # audio_head is stored [K-1][d'][V] (reference layout, a K-major matrix for x @ W); the decode path wants one
         # output row per wave, so it keeps a [K-1][V][d'] copy made from the current weights when the state is created
         self.head_t = m.block("audio_head.padded").transpose(1, 2).contiguous()
+
+    def fill_noise(self, noise=None):
+        """``noise``: K tensors [B, V] of Exp(1) draws (pins the sampler), or None for fresh draws from torch's generator."""
+        if noise is None:
+            self.noise_buf.exponential_(1)
+        else:
+            for i, q in enumerate(noise):
+                self.noise_buf[i].copy_(q.reshape(self.noise_buf[i].shape), non_blocking=True)
 
     def prefill(self, tokens, masks):
         e, m = self.e, self.e.m
@@ -670,10 +727,11 @@ class DecodeState:
         self.bb.pos.add_(1)
         return self.bb.step(self.h0)
 
-    def graph_frame(self, tokens, masks, temperature, topk):
+    def graph_frame(self, tokens, masks, temperature, topk, noise=None):
         """Replay one decode frame (~1.8 k kernel launches) as a single HIP graph.  The first decode frame runs eagerly
-        (warm-up: lazy function attributes, allocator), the second is captured, later ones are replays; positions live in
-        device memory, so the same graph serves every frame.  Re-captured when temperature / top-k change."""
+        (warm-up: lazy function attributes, allocator), the second is captured, later ones are replays; positions, input
+        tokens and the frame's noise live in persistent device buffers, so the same graph serves every frame.  Re-captured
+        when temperature / top-k change."""
         m = self.e.m
         if self.cur + 1 >= m.bb.max_seq_len:
             raise ValueError("sequence exceeds max_seq_len")
@@ -682,18 +740,20 @@ class DecodeState:
         if self.graph is None or self.graph_key != key:
             if self.warm < 1 or self.graph_key not in (None, key):
                 self.warm, self.graph, self.graph_key = 1, None, None
-                return self.e._decode_frame(self, tokens, masks, temperature, topk, None)
+                return self.e._decode_frame(self, tokens, masks, temperature, topk, noise)
             self.in_tok = tokens.to(torch.int64).clone()
             self.in_msk = masks.to(torch.uint8).clone()
+            self.fill_noise(noise)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.out_static = self.e._decode_frame(self, self.in_tok, self.in_msk, temperature, topk, None)
+                self.out_static = self.e._decode_frame_body(self, self.in_tok, self.in_msk, temperature, topk)
             self.graph, self.graph_key = g, key
             g.replay()
             return self.out_static.clone()
         self.in_tok.copy_(tokens)
         self.in_msk.copy_(masks)
+        self.fill_noise(noise)
         self.graph.replay()
         return self.out_static.clone()
 

@@ -48,6 +48,7 @@ _SIGS = {
     "csm_embed_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
     "csm_embed_bwd_sorted": ([_p, _p, _ll, _p, _p, _ll, _p, _p, _ll, _ll, _i, _p], _i),
     "csm_rows_add_bf16": ([_p, _p, _p, _ll, _i, _i, _p], _i),
+    "csm_rows_take_bf16": ([_p, _p, _p, _ll, _i, _p], _i),
     "csm_decoder_input_fwd": ([_p, _p, _p, _p, _p, _ll, _i, _i, _i, _p], _i),
     "csm_ce_fwd_bwd": ([_p, _p, _p, _p, _ll, _i, _i, _i, _f, _p], _i),
     "csm_reduce_sum_f32": ([_p, _ll, _f, _p, _p], _i),

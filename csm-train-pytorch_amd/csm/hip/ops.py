@@ -44,12 +44,15 @@ def gemm(A, B, C, R=None, transA=False, transB=False, alpha=1.0, batch=1, sA=0, 
     return C
 
 
-def linear_swiglu_fwd(x, w13, gu, act):
-    """gu[M,2F] = x w13^T with gate/up interleaved, act[M,F] = silu(gate)*up, one GEMM launch."""
+def linear_swiglu_fwd(x, w13, gu, act, residual=None):
+    """gu[M,2F] = x w13^T (+ residual) with gate/up interleaved, act[M,F] = silu(gate)*up, one GEMM launch.
+    ``residual`` [M,2F] (may be ``gu`` itself) is how LoRA adapters on w1 / w3 join: their product is written first."""
     pa, M, K, lda = _mat(x)
     pb, N, Kb, ldb = _mat(w13)
     assert K == Kb and gu.shape == (M, N) and act.shape == (M, N // 2) and gu.is_contiguous() and act.is_contiguous()
-    check(lib.csm_gemm_bf16_ex(pa, pb, gu.data_ptr(), None, M, N, K, lda, ldb, N, 0, 0, 0, 0, 1.0, 1, 0, 0, 0, 0, 1, None,
+    pr, ldr = (None, 0) if residual is None else (residual.data_ptr(), residual.stride(0))
+    assert residual is None or (residual.shape == (M, N) and residual.stride(1) == 1 and residual.dtype == BF16)
+    check(lib.csm_gemm_bf16_ex(pa, pb, gu.data_ptr(), pr, M, N, K, lda, ldb, N, ldr, 0, 0, 0, 1.0, 1, 0, 0, 0, 0, 1, None,
                                act.data_ptr(), N // 2, _stream()), "csm_gemm_bf16_ex(swiglu fwd)")
 
 
@@ -206,6 +209,14 @@ def embed_bwd_sorted(sorted_rows, src_index, dh, dseq, g_text, g_audio):
 def rows_add_bf16(dst, rows_i32, src, src_stride_rows):
     check(lib.csm_rows_add_bf16(dst.data_ptr(), rows_i32.data_ptr(), src.data_ptr(), rows_i32.numel(), int(src_stride_rows),
                                 dst.shape[1], _stream()), "csm_rows_add_bf16")
+
+
+def rows_take_bf16(table, rows_i32, out):
+    """out[n] = table[rows[n]]; table[rows[n]] = 0 (unique rows; negative = padding -> zero row)."""
+    assert rows_i32.dtype == torch.int32 and rows_i32.is_contiguous() and out.is_contiguous() and out.shape == (rows_i32.numel(), table.shape[1])
+    check(lib.csm_rows_take_bf16(table.data_ptr(), rows_i32.data_ptr(), out.data_ptr(), rows_i32.numel(), table.shape[1], _stream()),
+          "csm_rows_take_bf16")
+    return out
 
 
 def decoder_input_fwd(hidden, rows_i32, codes, audio_emb, out, audio_vocab):

@@ -66,6 +66,9 @@ FLAVORS = {
     # small shapes for tests (head_dim kept at the real 64 / 128)
     "llama-tiny-backbone": lambda: StackConfig(256, 2, 4, 2, 512, max_seq_len=128),
     "llama-tiny-decoder": lambda: StackConfig(256, 2, 2, 1, 512, max_seq_len=128),
+    # ONE layer at the full CSM-1B / CSM-100M widths: the full-shape parity fixtures (tests/golden/make_golden_full.py)
+    "llama-1B-L1": lambda: StackConfig(2048, 1, 32, 8, 8192),
+    "llama-100M-L1": lambda: StackConfig(1024, 1, 8, 2, 8192),
 }
 
 

@@ -39,11 +39,17 @@ def init_nccl(rank: int, world: int, local: int):
     """RCCL process group bound to this rank's GPU, its collectives on a high-priority stream: the all-reduce's few
     workgroups should get CUs as GEMM workgroups retire instead of queueing behind the whole backward."""
     kw = dict(rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    opts = None
     try:
         opts = dist.ProcessGroupNCCL.Options()
         opts.is_high_priority_stream = True
+    except AttributeError as e:      # a torch build without the option: say so, do not silently change the schedule
+        import warnings
+        warnings.warn(f"RCCL process group WITHOUT a high-priority stream ({e!r}): gradient all-reduces will queue behind "
+                      "the backward's GEMMs and the exposed communication time grows", RuntimeWarning, stacklevel=2)
+    if opts is not None:
         dist.init_process_group("nccl", pg_options=opts, **kw)
-    except (AttributeError, TypeError):
+    else:
         dist.init_process_group("nccl", **kw)
 
 
@@ -68,6 +74,9 @@ class GradSync:
         self.handles = []
         self.launch_log: List[tuple] = []
         self.sparse: Optional[dict] = None        # text-embedding rows exchanged as lists (set by for_model on the GPU)
+        self.timing = False                       # record how long the compute stream waits for the collectives (bench.py)
+        self.exposed_ms: List[float] = []
+        self._wait_events: List[tuple] = []
 
     @staticmethod
     def active() -> bool:
@@ -97,7 +106,10 @@ class GradSync:
         if ("embeddings", -1) in buckets and model.grad_arena.is_cuda and os.environ.get("CSM_DP_DENSE_EMBEDDINGS") != "1":
             t = slots["text_embeddings.weight"]
             buckets[("embeddings", -1)] = [sl for sl in buckets[("embeddings", -1)] if sl != (t.offset, t.numel)]
-            sparse = dict(slice=(t.offset, t.numel), D=model.bb.embed_dim, seen=[], rows=None, counts=None)
+            cap = int(os.environ.get("CSM_DP_TEXT_ROWS_CAP", cls.TEXT_ROWS_CAP))
+            sparse = dict(slice=(t.offset, t.numel), D=model.bb.embed_dim, seen=[], cap=cap, n_rows=t.shape[0],
+                          overflow=torch.zeros(1, dtype=torch.int32, device=model.grad_arena.device),
+                          host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=None)
         merged = {k: cls._merge(v) for k, v in buckets.items()}
         extra = [model.lora.grad_arena] if model.lora is not None else []
         gs = cls(model.grad_arena, merged, group, extra)
@@ -116,61 +128,84 @@ class GradSync:
                 out.append((off, n))
         return out
 
-    SPARSE_MAX_ROWS = 16384       # beyond this many touched text rows per rank the dense all-reduce is used instead
+    TEXT_ROWS_CAP = 2048          # rows of the text-embedding gradient a rank may touch per optimiser step (CSM_DP_TEXT_ROWS_CAP)
 
     def note_batch(self, tokens: torch.Tensor, masks: torch.Tensor):
-        """Remember which text-embedding rows this micro-batch touches (column K of the live text slots)."""
+        """Remember which text-embedding rows this micro-batch touches (column K of the live text slots).  No host
+        sync: masked-out slots become a sentinel id and the sizes stay static."""
         if self.sparse is None:
             return
+        sp = self.sparse
         k = tokens.shape[-1] - 1
-        t, mk = tokens[..., k].reshape(-1), masks[..., k].reshape(-1).bool()
-        self.sparse["seen"].append(t[mk].to(self.flat.device, torch.int64))
+        t = tokens[..., k].reshape(-1).to(self.flat.device, torch.int64, non_blocking=True)
+        mk = masks[..., k].reshape(-1).to(self.flat.device, non_blocking=True).bool()
+        sp["seen"].append(torch.where(mk, t, torch.full_like(t, sp["n_rows"])))
 
     def arm(self, enabled: bool = True):
         """Call before a backward: ``enabled`` only on the micro-batch that ends an accumulation window."""
         self.armed = enabled and self.world_size > 1
         self.done = set()
         self.handles = []
-        if self.armed and self.sparse is not None:
-            # union of the window's text rows and every rank's count, exchanged now - before the backward - so that the
-            # one host sync this needs does not sit at the end of the step behind all the queued collectives
-            sp = self.sparse
-            rows = torch.unique(torch.cat(sp["seen"])) if sp["seen"] else torch.empty(0, dtype=torch.int64, device=self.flat.device)
-            sp["seen"] = []
-            cnt = torch.tensor([rows.numel()], dtype=torch.int64, device=self.flat.device)
-            got = [torch.zeros_like(cnt) for _ in range(self.world_size)]
-            dist.all_gather(got, cnt, group=self.group)
-            sp["rows"], sp["counts"] = rows.to(torch.int32), [int(x) for x in got]
+        sp = self.sparse
+        if sp is not None and sp["event"] is not None and sp["event"].query():
+            # the previous step's overflow flag has reached the host (asynchronous copy): look at it without waiting
+            sp["event"] = None
+            if int(sp["host"][0]) > 0:
+                raise RuntimeError(
+                    f"data-parallel text-embedding exchange: a rank touched more than {sp['cap']} distinct text rows in one "
+                    "optimiser step, the previous step's embedding gradients are incomplete.  Raise CSM_DP_TEXT_ROWS_CAP or set "
+                    "CSM_DP_DENSE_EMBEDDINGS=1 (dense 525 MB all-reduce).")
 
     def _launch_text_rows(self):
-        """All-gather (row id, gradient row) of the text-embedding rows each rank touched and add them in rank order."""
+        """Fixed-capacity exchange of the touched text-embedding gradient rows: every rank sends ``cap`` (row id, gradient
+        row) slots (id -1 = unused), all-gathers everybody's, and adds them in rank order - bit-identical tables on every
+        rank, as after an all-reduce, for a few MB instead of 525.  Every size is static, so nothing here waits for the
+        host: an overflow (more than ``cap`` distinct rows on some rank) raises a device flag that ``arm`` reads a step
+        later through an asynchronous copy."""
+        from ..hip import ops
         sp = self.sparse
         o, n = sp["slice"]
-        counts, D = sp["counts"], sp["D"]
-        if max(counts) > self.SPARSE_MAX_ROWS:
-            self._launch([self.flat[o:o + n]], ("embeddings", "text-dense"))
-            return
-        from ..hip import ops
+        D, cap, n_rows = sp["D"], sp["cap"], sp["n_rows"]
         self.launch_log.append(("embeddings", "text-rows"))
-        cap = max(64, (max(counts) + 63) // 64 * 64)
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
             g = self.flat[o:o + n].view(-1, D)
-            rows, mine = sp["rows"], sp["rows"].numel()
-            send_r = torch.full((cap,), -1, dtype=torch.int32, device=g.device)
-            send_g = torch.zeros(cap, D, dtype=g.dtype, device=g.device)
-            if mine:
-                send_r[:mine] = rows
-                send_g[:mine] = g[rows.long()]
-            all_r = [torch.empty_like(send_r) for _ in range(self.world_size)]
-            all_g = [torch.empty_like(send_g) for _ in range(self.world_size)]
-            dist.all_gather(all_r, send_r, group=self.group)
-            dist.all_gather(all_g, send_g, group=self.group)
-            if mine:
-                g.index_fill_(0, rows.long(), 0)
-            for r in range(self.world_size):                      # fixed order: every rank computes the same bits
-                if counts[r]:
-                    ops.rows_add_bf16(g, all_r[r][:counts[r]].contiguous(), all_g[r], 1)
+            dev = g.device
+            send_r = torch.full((cap + 1,), -1, dtype=torch.int32, device=dev)
+            if sp["seen"]:
+                ids = torch.cat(sp["seen"]).sort().values                       # sentinel n_rows sorts last
+                first = torch.ones_like(ids, dtype=torch.bool)
+                first[1:] = ids[1:] != ids[:-1]
+                first &= ids < n_rows
+                pos = torch.cumsum(first, 0) - 1
+                slot = torch.where(first & (pos < cap), pos, torch.full_like(pos, cap))   # overflow and duplicates -> scratch slot
+                send_r.scatter_(0, slot, ids.to(torch.int32))
+                sp["overflow"].copy_((first.sum() > cap).to(torch.int32).reshape(1))
+            else:
+                sp["overflow"].zero_()
+            sp["seen"] = []
+            send_r = send_r[:cap].contiguous()
+            send_g = torch.empty(cap, D, dtype=g.dtype, device=dev)
+            ops.rows_take_bf16(g, send_r, send_g)                                # lift own rows out of the table (zeroes them)
+            all_r = torch.empty(self.world_size * cap, dtype=torch.int32, device=dev)
+            all_g = torch.empty(self.world_size * cap, D, dtype=g.dtype, device=dev)
+            self._all_gather(all_r, send_r)
+            self._all_gather(all_g, send_g)
+            for r in range(self.world_size):                                     # fixed order: every rank computes the same bits
+                ops.rows_add_bf16(g, all_r[r * cap:(r + 1) * cap], all_g[r * cap:(r + 1) * cap], 1)
+            dist.all_reduce(sp["overflow"], op=dist.ReduceOp.MAX, group=self.group)
+            sp["host"].copy_(sp["overflow"], non_blocking=True)
+            sp["event"] = torch.cuda.Event()
+            sp["event"].record()
+
+    def _all_gather(self, out: torch.Tensor, part: torch.Tensor):
+        """out = concatenation over the ranks of ``part`` (one flat collective on RCCL; the list form where the backend -
+        gloo in the one-GPU rehearsal tests - lacks it)."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, part, group=self.group)
+        else:
+            n = part.shape[0]
+            dist.all_gather([out[r * n:(r + 1) * n] for r in range(self.world_size)], part, group=self.group)
 
     def _launch(self, tensors: List[torch.Tensor], key):
         self.launch_log.append(key)
@@ -208,8 +243,60 @@ class GradSync:
         if self.extra:
             self._launch(list(self.extra), ("extra", -1))
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream()
+            if self.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.comm_stream)
+                e1.record(cur)
+                self._wait_events.append((e0, e1))
+            else:
+                cur.wait_stream(self.comm_stream)
         else:
             for h in self.handles:
                 h.wait()
         self.armed = False
+
+    def exposed_comm_ms(self) -> List[float]:
+        """Per optimiser step: how long the compute stream sat waiting for the communication stream at the end of the
+        backward (``timing`` must be on).  Synchronises."""
+        if self._wait_events:
+            torch.cuda.synchronize()
+            self.exposed_ms += [a.elapsed_time(b) for a, b in self._wait_events]
+            self._wait_events = []
+        return self.exposed_ms
+
+    # ------------------------------------------------------------------ replica consistency
+    @staticmethod
+    def broadcast_parameters(model, src: int = 0, group=None):
+        """Rank ``src``'s parameters to every rank (start of training / after loading a checkpoint): replicas must not
+        depend on every rank having drawn the same random init or read the same file."""
+        if not GradSync.active():
+            return
+        dist.broadcast(model.arena, src=src, group=group)
+        if model.lora is not None:
+            dist.broadcast(model.lora.arena, src=src, group=group)
+
+    @staticmethod
+    def assert_replicas_equal(model, group=None, what: str = "parameters"):
+        """Cheap divergence check: two checksums of the bf16 arena (sum of the raw 16-bit words, sum of squares of the
+        values) must agree on every rank.  One host sync - call it at start-up / checkpoint time, not per step."""
+        if not GradSync.active():
+            return
+        a = model.arena
+        chk = torch.stack([a.view(torch.int16).to(torch.int64).sum().double(), a.double().square().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"data-parallel replicas diverged: {what} checksums differ across ranks ({lo.tolist()} .. {hi.tolist()})")
+
+    @staticmethod
+    def mean_scalar(x, group=None) -> float:
+        """Mean over the ranks of a logged scalar (training / validation loss): SURVEY 8e, C2."""
+        if not GradSync.active():
+            return float(x)
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return float(t) / dist.get_world_size(group)

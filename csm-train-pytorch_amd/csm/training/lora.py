@@ -36,14 +36,21 @@ class LoRAAdapter:
             return x
         return ops.dropout_bf16(x, torch.empty(x.shape, dtype=BF16, device=x.device), self.dropout, self._draw)
 
-    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        """y += scaling * (drop(x) A^T) B^T (+ bias); returns t = drop(x) A^T (kept for the backward)."""
+    def project(self, x: torch.Tensor, t: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """t = drop(x) A^T  [M, r] (draws this forward's dropout mask); ``t`` may be a column block of a wider buffer."""
         self._draw = None
         if self.dropout > 0 and self.state.training:
             self.state.draws += 1
             self._draw = (self.seed * 0x9E3779B1 + self.state.draws * 0x85EBCA77) & (2 ** 63 - 1)
-        t = torch.empty(x.shape[0], self.r, dtype=BF16, device=x.device)
+        if t is None:
+            t = torch.empty(x.shape[0], self.r, dtype=BF16, device=x.device)
         ops.gemm(self._dropped(x), self.A, t)
+        return t
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """y += scaling * (drop(x) A^T) B^T (+ bias); returns t = drop(x) A^T (kept for the backward).  The second
+        product accumulates into the frozen projection's output in its GEMM epilogue (C = R + alpha * acc, R = C = y)."""
+        t = self.project(x)
         ops.gemm(t, self.B, y, y, alpha=self.scaling)
         if self.bias is not None:
             ops.bias_add_bf16(y, self.bias)
@@ -89,9 +96,13 @@ class LoRAState:
                  target_layers: Optional[List[int]], use_bias: bool, seed: int = 0):
         if not 0.0 <= float(dropout) < 1.0:
             raise ValueError("lora_dropout must be in [0, 1)")
-        if r % 8 != 0:
-            raise ValueError("lora_r must be a multiple of 8 (MFMA k-step / 16-byte rows)")
-        self.r, self.alpha, self.dropout, self.scaling = r, alpha, dropout, alpha / r
+        if r < 1:
+            raise ValueError("lora_r must be positive")
+        # any rank (the reference documents r = 4 and its CLI accepts any --lora-r): A / B are stored padded to the next
+        # multiple of 8 (16-byte rows, MFMA k-step) with the padding rows of A and columns of B at zero.  The padding
+        # stays exactly zero under training - its gradients are products with those zeros - so the padded adapter IS the
+        # rank-r adapter; the reference-shaped [r, in] / [out, r] tensors are views (named_tensors).
+        self.r, self.r_pad, self.alpha, self.dropout, self.scaling = r, (r + 7) // 8 * 8, alpha, dropout, alpha / r
         self.target_modules, self.target_layers, self.use_bias = list(target_modules), target_layers, use_bias
         self.training, self.draws = True, 0        # dropout is live only while training; draws counts masks drawn
         plan = []
@@ -109,7 +120,8 @@ class LoRAState:
                     sub = "attn" if mod in ATTN else "mlp"
                     out_f, in_f = dims[mod]
                     plan.append((prefix, i, mod, f"{prefix}.layers.{i}.{sub}.{mod}", out_f, in_f))
-        total = sum(r * in_f + out_f * r + (out_f if use_bias else 0) for *_, out_f, in_f in plan)
+        rp = self.r_pad
+        total = sum(rp * in_f + out_f * rp + (out_f if use_bias else 0) for *_, out_f, in_f in plan)
         total = (total + 7) // 8 * 8
         dev = model.device
         self.arena = torch.zeros(total, dtype=BF16, device=dev)
@@ -119,17 +131,17 @@ class LoRAState:
         g.manual_seed(seed)
         off = 0
         for prefix, i, mod, name, out_f, in_f in plan:
-            A = self.arena[off:off + r * in_f].view(r, in_f)
-            gA = self.grad_arena[off:off + r * in_f].view(r, in_f)
-            off += r * in_f
-            B = self.arena[off:off + out_f * r].view(out_f, r)
-            gB = self.grad_arena[off:off + out_f * r].view(out_f, r)
-            off += out_f * r
+            A = self.arena[off:off + rp * in_f].view(rp, in_f)
+            gA = self.grad_arena[off:off + rp * in_f].view(rp, in_f)
+            off += rp * in_f
+            B = self.arena[off:off + out_f * rp].view(out_f, rp)
+            gB = self.grad_arena[off:off + out_f * rp].view(out_f, rp)
+            off += out_f * rp
             bias = gbias = None
             if use_bias:
                 bias, gbias = self.arena[off:off + out_f], self.grad_arena[off:off + out_f]
                 off += out_f
-            A.copy_((torch.randn(r, in_f, generator=g, device=dev) / math.sqrt(in_f)).to(BF16))
+            A[:r].copy_((torch.randn(r, in_f, generator=g, device=dev) / math.sqrt(in_f)).to(BF16))
             self.adapters[(prefix, i, mod)] = LoRAAdapter(name, A, B, gA, gB, self.scaling, bias, gbias, dropout,
                                                           seed * 1000003 + len(self.adapters), self)
 
@@ -138,8 +150,8 @@ class LoRAState:
 
     def named_tensors(self):
         for ad in self.adapters.values():
-            yield f"{ad.name}.lora_A", ad.A
-            yield f"{ad.name}.lora_B", ad.B
+            yield f"{ad.name}.lora_A", ad.A[:self.r]            # reference shapes: A [r, in], B [out, r] (lora.py:62-66)
+            yield f"{ad.name}.lora_B", ad.B[:, :self.r]
             if ad.bias is not None:
                 yield f"{ad.name}.lora_bias", ad.bias
 

@@ -84,6 +84,12 @@ class CSMLoRATrainer:
     def prepare_optimizer(self):
         """Reference lora_trainer.py:305-372: Adam(lr) over ``model.get_lora_params()`` only (no weight decay)."""
         n = self.model.lora.num_params()
+        if GradSync.active():
+            GradSync.broadcast_parameters(self.model)      # base weights and adapters of rank 0 everywhere, before the master copy
+            # adapter dropout must differ between ranks (each rank sees its own shard): fold the rank into the seeds
+            rk = torch.distributed.get_rank()
+            for ad in self.model.lora.adapters.values():
+                ad.seed = ad.seed * 31 + rk
         self.optimizer = FusedAdamW(self.model, {}, lora_lr=self.learning_rate, lora_weight_decay=0.0)
         base = sum(self.model.group_range(g)[1] for g in ("backbone", "decoder"))
         self.logger.info(f"Training with {n:,} LoRA parameters ({100.0 * n / base:.3f}% of the transformer stacks)")
@@ -117,28 +123,44 @@ class CSMLoRATrainer:
         if resume_from:
             self.load_lora_weights(resume_from)
         self.logger.info("Starting LoRA training")
+        # data parallel (new capability): rank r takes batches r, r + world, r + 2 world, ... of the get_batch protocol, so
+        # the ranks see disjoint data and one optimiser step covers world * batch_size sequences; replicas are identical,
+        # so rank 0 alone writes files
+        world = torch.distributed.get_world_size() if GradSync.active() else 1
+        rank = torch.distributed.get_rank() if GradSync.active() else 0
+
+        def save(path):
+            if rank == 0:
+                self.save_model(path, "lora")
+            if world > 1:
+                torch.distributed.barrier()
+
         for epoch in range(self.epoch, self.epoch + epochs):
             t0 = time.time()
             losses = []
-            n_batches = len(train_dataset) // batch_size
+            n_batches = len(train_dataset) // (batch_size * world)
             for batch_idx in range(n_batches):
-                loss = self.train_step(train_dataset.get_batch(batch_idx, batch_size))
+                loss = self.train_step(train_dataset.get_batch(batch_idx * world + rank, batch_size))
                 losses.append(loss)
                 self.global_step += 1
                 if val_dataset is not None and self.global_step % val_every == 0:
-                    val_loss = self._validate(val_dataset, batch_size)
-                    self.logger.info(f"Epoch {epoch + 1}, Step {self.global_step}, Val Loss: {val_loss:.6f}")
+                    val_loss = GradSync.mean_scalar(self._validate(val_dataset, batch_size))
+                    if rank == 0:
+                        self.logger.info(f"Epoch {epoch + 1}, Step {self.global_step}, Val Loss: {val_loss:.6f}")
                     if val_loss < self.best_loss:
                         self.best_loss = val_loss
-                        self.save_model(str(self.output_dir / "best"), "lora")
+                        save(str(self.output_dir / "best"))
                 if self.global_step % save_every == 0:
-                    self.save_model(str(self.output_dir / f"checkpoint_step_{self.global_step}"), "lora")
+                    save(str(self.output_dir / f"checkpoint_step_{self.global_step}"))
             avg = float(torch.stack(losses).mean()) if losses else float("nan")
+            avg = GradSync.mean_scalar(avg)
             if not math.isfinite(avg):
                 raise FloatingPointError(f"non-finite training loss in epoch {epoch + 1}")
-            self.logger.info(f"Epoch {epoch + 1} completed in {time.time() - t0:.2f}s, Avg Loss: {avg:.6f}")
+            if rank == 0:
+                self.logger.info(f"Epoch {epoch + 1} completed in {time.time() - t0:.2f}s, Avg Loss: {avg:.6f}")
             self.epoch = epoch + 1
-        self.logger.info("Training completed")
+        if rank == 0:
+            self.logger.info("Training completed")
         return self.best_loss
 
     def _validate(self, val_dataset, batch_size: int) -> float:

@@ -124,10 +124,21 @@ class FusedAdamW:
                 "state": {n: {k: t.cpu() for k, t in st.items()} for n, st in self.state.items()}}
 
     def load_state_dict(self, sd):
+        """Groups are matched by NAME (backbone / decoder / embeddings / other / lora), never by position: resuming with
+        different freeze flags must fail loudly instead of giving a group another group's learning rate."""
+        saved_by_name = {g["name"]: g for g in sd["groups"]}
+        mine = [g["name"] for g in self.param_groups]
+        if sorted(saved_by_name) != sorted(mine) or sorted(sd["state"]) != sorted(mine):
+            raise ValueError(f"optimizer state was saved for parameter groups {sorted(saved_by_name)} but this optimizer has "
+                             f"{sorted(mine)} (different freeze flags / LoRA setting?)")
+        for g in self.param_groups:
+            saved = saved_by_name[g["name"]]
+            if (saved["offset"], saved["numel"]) != (g["offset"], g["numel"]):
+                raise ValueError(f"optimizer group {g['name']!r}: saved range {saved['offset']}+{saved['numel']} != {g['offset']}+{g['numel']}")
         self.step_count = sd["step"]
         for n, st in sd["state"].items():
-            if n in self.state:
-                for k, t in st.items():
-                    self.state[n][k].copy_(t)
-        for g, saved in zip(self.param_groups, sd["groups"]):
+            for k, t in st.items():
+                self.state[n][k].copy_(t)
+        for g in self.param_groups:
+            saved = saved_by_name[g["name"]]
             g["lr"], g["weight_decay"] = saved["lr"], saved["weight_decay"]

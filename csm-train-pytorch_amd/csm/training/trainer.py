@@ -75,6 +75,10 @@ class CSMTrainer:
                "decoder": self.learning_rate * self.decoder_lr_multiplier,
                "embeddings": self.learning_rate * self.embedding_lr_multiplier,
                "other": self.learning_rate}
+        if GradSync.active():
+            # replicas start from rank 0's parameters (do not rely on equal seeds / files), BEFORE the optimiser takes its
+            # fp32 master copy of them
+            GradSync.broadcast_parameters(m)
         self.optimizer = FusedAdamW(m, lrs, weight_decay=self.weight_decay)
         total = sum(p.numel() for n, p in m.named_parameters()
                     if m.trainable["backbone" if "backbone" in n else "decoder" if "decoder" in n else
@@ -111,6 +115,8 @@ class CSMTrainer:
         if getattr(self, "ignore_padding", False):
             from ..data.training_data import IGNORE_INDEX
             pad = self.model.target_ignore_index = IGNORE_INDEX
+        sampler = None
+        rank0 = (not GradSync.active()) or torch.distributed.get_rank() == 0
         if GradSync.active():
             # data parallel: every rank walks its own shard of the dataset (new capability, see training/dp.py)
             from functools import partial
@@ -130,12 +136,22 @@ class CSMTrainer:
             self.logger.info(f"Resuming from checkpoint: {resume_from}")
             meta = load_checkpoint(resume_from, self.model, self.optimizer, self.device)
             self.epoch, self.global_step, self.best_loss = meta["epoch"], meta["global_step"], meta["loss"]
+            GradSync.assert_replicas_equal(self.model, what=f"parameters after resuming from {resume_from}")
         self.logger.info("Starting training")
         self.model.train()
         avg_loss = float("nan")
+        def save(epoch_, loss_, name="checkpoint"):
+            # replicas are bit-identical: one writer (rank 0), the others wait so that nobody races ahead into a resume
+            if rank0:
+                save_checkpoint(self.model, self.optimizer, epoch_, self.global_step, loss_, str(self.output_dir), name)
+            if GradSync.active():
+                torch.distributed.barrier()
+
         for epoch in range(self.epoch, self.epoch + epochs):
             t0 = time.time()
             losses = []
+            if sampler is not None:
+                sampler.set_epoch(epoch)                 # a different shuffle every epoch
             for batch_idx, batch in enumerate(train_loader):
                 boundary = (batch_idx + 1) % accumulation_steps == 0
                 loss, _ = self.train_step(batch, accumulation_steps, boundary, max_grad_norm)
@@ -144,20 +160,24 @@ class CSMTrainer:
                     continue
                 self.global_step += 1
                 if val_loader is not None and self.global_step % val_every == 0:
-                    val_loss = self._validate(val_loader)
-                    self.logger.info(f"Epoch {epoch + 1}, Step {self.global_step}, Val Loss: {val_loss:.6f}")
+                    val_loss = GradSync.mean_scalar(self._validate(val_loader))      # every rank scores the same set: mean == each
+                    if rank0:
+                        self.logger.info(f"Epoch {epoch + 1}, Step {self.global_step}, Val Loss: {val_loss:.6f}")
                     if val_loss < self.best_loss:
                         self.best_loss = val_loss
-                        save_checkpoint(self.model, self.optimizer, epoch + 1, self.global_step, val_loss, str(self.output_dir), "best")
+                        save(epoch + 1, val_loss, "best")
                 if self.global_step % save_every == 0:
-                    recent = float(torch.stack(losses[-accumulation_steps:]).mean())
-                    save_checkpoint(self.model, self.optimizer, epoch + 1, self.global_step, recent, str(self.output_dir))
+                    recent = GradSync.mean_scalar(float(torch.stack(losses[-accumulation_steps:]).mean()))
+                    save(epoch + 1, recent)
             avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")   # one host sync per epoch
-            self.logger.info(f"Epoch {epoch + 1} completed in {time.time() - t0:.2f}s, Avg Loss: {avg_loss:.6f}")
-            save_checkpoint(self.model, self.optimizer, epoch + 1, self.global_step, avg_loss, str(self.output_dir), f"epoch_{epoch + 1}")
+            avg_loss = GradSync.mean_scalar(avg_loss)                                    # over the ranks' shards
+            if rank0:
+                self.logger.info(f"Epoch {epoch + 1} completed in {time.time() - t0:.2f}s, Avg Loss: {avg_loss:.6f}")
+            save(epoch + 1, avg_loss, f"epoch_{epoch + 1}")
             self.epoch = epoch + 1
-        self.logger.info("Training completed")
-        save_checkpoint(self.model, self.optimizer, self.epoch, self.global_step, avg_loss, str(self.output_dir), "final")
+        if rank0:
+            self.logger.info("Training completed")
+        save(self.epoch, avg_loss, "final")
         return self.best_loss
 
     def _validate(self, val_loader) -> float:

@@ -78,8 +78,10 @@ def save_checkpoint(model, optimizer, epoch: int, global_step: int, loss: float,
         "loss": float(loss),
     }
     path = os.path.join(save_dir, f"{name}_epoch{epoch}_step{global_step}.pt")
-    torch.save(ckpt, path)
-    torch.save(ckpt, os.path.join(save_dir, f"{name}_latest.pt"))
+    for dst in (path, os.path.join(save_dir, f"{name}_latest.pt")):
+        tmp = dst + ".tmp"                       # write-then-rename: a reader (or a crash) never sees half a checkpoint
+        torch.save(ckpt, tmp)
+        os.replace(tmp, dst)
     return path
 
 

@@ -187,7 +187,9 @@ extern "C" int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     if (!transB) CSM_REQUIRE((K & 7) == 0, "csm_gemm_bf16: K must be a multiple of 8 when B is [N][K] (K=%d)", K);
     else CSM_REQUIRE((N & 7) == 0, "csm_gemm_bf16: N must be a multiple of 8 when B is [K][N] (N=%d)", N);
     CSM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= (epilogue == 2 ? 2 * N : N), "csm_gemm_bf16: leading dimension too small");
-    if (epilogue == 1) CSM_REQUIRE(!out_f32 && aux_out && (N & 3) == 0 && (ldc & 3) == 0 && ld_aux >= N / 2 && (ld_aux & 1) == 0 && !R, "csm_gemm_bf16_ex: bad SwiGLU-forward epilogue arguments");
+    // (R is allowed with the SwiGLU-forward epilogue: gate/up = alpha * acc + R, activation from the sum - the port through
+    //  which a LoRA adapter's (alpha/r) t B^T, written first, joins the frozen w1/w3 product without leaving the fused path)
+    if (epilogue == 1) CSM_REQUIRE(!out_f32 && aux_out && (N & 3) == 0 && (ldc & 3) == 0 && ld_aux >= N / 2 && (ld_aux & 1) == 0, "csm_gemm_bf16_ex: bad SwiGLU-forward epilogue arguments");
     if (epilogue == 2) CSM_REQUIRE(!out_f32 && aux_in && (N & 3) == 0 && (ldc & 7) == 0 && (ld_aux & 7) == 0 && ld_aux >= 2 * N && !R && ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)C & 15) == 0, "csm_gemm_bf16_ex: bad SwiGLU-backward epilogue arguments");
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 2, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 3 && K % 64 == 0 && M >= 8 && N >= 8))

@@ -377,12 +377,13 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const long long* 
     }
 }
 
-// dst[rows[n]][:] += src[n * src_stride_rows][:]   (rows are unique: no atomics; one wave per n)
+// dst[rows[n]][:] += src[n * src_stride_rows][:]   (rows are unique: no atomics; one wave per n; rows[n] < 0 = padding, skipped)
 __global__ __launch_bounds__(256) void rows_add_kernel(bf16_t* __restrict__ dst, const int* __restrict__ rows,
                                                        const bf16_t* __restrict__ src, long long N, int src_stride_rows, int D) {
     const int lane = threadIdx.x & 63;
     const long long n = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= N) return;
+    if (rows[n] < 0) return;
     bf16_t* d = dst + (size_t)rows[n] * D;
     const bf16_t* s = src + (size_t)n * src_stride_rows * D;
     for (int c0 = lane * 8; c0 < D; c0 += 512) {
@@ -392,6 +393,25 @@ __global__ __launch_bounds__(256) void rows_add_kernel(bf16_t* __restrict__ dst,
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += b[j];
         *reinterpret_cast<U4*>(d + c0) = pack8(a);
+    }
+}
+
+// out[n][:] = table[rows[n]][:]; table[rows[n]][:] = 0   (rows unique; rows[n] < 0 = padding: out[n] = 0).  The data-parallel
+// exchange of the text-embedding gradient rows: a rank lifts the rows it touched out of its gradient table, every rank
+// then adds all ranks' rows back in rank order (csm_rows_add_bf16), which leaves bit-identical tables everywhere.
+__global__ __launch_bounds__(256) void rows_take_kernel(bf16_t* __restrict__ table, const int* __restrict__ rows,
+                                                        bf16_t* __restrict__ out, long long N, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int r = rows[n];
+    bf16_t* o = out + (size_t)n * D;
+    const U4 z = {0u, 0u, 0u, 0u};
+    for (int c0 = lane * 8; c0 < D; c0 += 512) {
+        if (r < 0) { *reinterpret_cast<U4*>(o + c0) = z; continue; }
+        bf16_t* t = table + (size_t)r * D + c0;
+        *reinterpret_cast<U4*>(o + c0) = *reinterpret_cast<const U4*>(t);
+        *reinterpret_cast<U4*>(t) = z;
     }
 }
 
@@ -666,6 +686,13 @@ extern "C" int csm_rows_add_bf16(void* dst, const int* rows, const void* src, lo
     hipLaunchKernelGGL(rows_add_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, (bf16_t*)dst, rows, (const bf16_t*)src,
                        N, src_stride_rows, D);
     CSM_CHECK_LAUNCH("csm_rows_add_bf16");
+    return 0;
+}
+
+extern "C" int csm_rows_take_bf16(void* table, const int* rows, void* out, long long N, int D, hipStream_t stream) {
+    CSM_REQUIRE(table && rows && out && N > 0 && (D & 7) == 0, "csm_rows_take_bf16: bad arguments");
+    hipLaunchKernelGGL(rows_take_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, (bf16_t*)table, rows, (bf16_t*)out, N, D);
+    CSM_CHECK_LAUNCH("csm_rows_take_bf16");
     return 0;
 }
 

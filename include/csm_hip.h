@@ -104,8 +104,13 @@ int csm_embed_fwd(const long long* tokens, const uint8_t* mask, const void* text
 int csm_embed_bwd_sorted(const long long* sorted_rows, const long long* src_index, long long n_occ, const void* dh,
                          const void* dseq, long long M, void* g_text, void* g_audio, long long text_rows, long long n_rows,
                          int D, csm_stream_t stream);
-/* dst[rows[n]] += src[n * src_stride_rows] for unique rows (scatter of the decoder's position-0 gradient) */
+/* dst[rows[n]] += src[n * src_stride_rows] for unique rows (scatter of the decoder's position-0 gradient); rows[n] < 0 is
+ * padding and is skipped */
 int csm_rows_add_bf16(void* dst, const int* rows, const void* src, long long N, int src_stride_rows, int D, csm_stream_t stream);
+/* out[n] = table[rows[n]], table[rows[n]] = 0 for unique rows (rows[n] < 0: out[n] = 0).  New capability (the reference has
+ * no distributed code): the fixed-capacity exchange of touched text-embedding gradient rows between
+ * data-parallel ranks (csm/training/dp.py), which replaces a 525 MB all-reduce of reference model.py:119's table. */
+int csm_rows_take_bf16(void* table, const int* rows, void* out, long long N, int D, csm_stream_t stream);
 
 /* depth-decoder teacher forcing (model.py:175-189): out[n][0]=hidden[rows[n]], out[n][i]=audio_emb[code_{i-1}+(i-1)V] */
 int csm_decoder_input_fwd(const void* hidden, const int* rows, const long long* codes, const void* audio_emb, void* out,

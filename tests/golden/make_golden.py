@@ -198,7 +198,7 @@ def main():
     cur_t, cur_m, cur_p = pt, pm, pos
     all_t, all_m = pt, pm
     K = TINY.n_codebooks
-    for step in range(3):
+    for step in range(8):
         torch.manual_seed(1000 + step)
         with torch.no_grad():
             f_ref = model.generate_frame(cur_t, cur_m, cur_p, 0.9, 10)
@@ -213,6 +213,26 @@ def main():
         all_t, all_m = torch.cat([all_t, nxt], 1), torch.cat([all_m, nm], 1)
         cur_t, cur_m, cur_p = nxt, nm, cur_p[:, -1:] + 1
     meta["generate_frames"] = torch.cat(frames_ref).tolist()
+    # the same for a batch of two prompts (rows decode independently; the noise of a frame is drawn [B, V] per codebook)
+    model.reset_caches()
+    cur_t, cur_m, cur_p = tokens[:, :n_prompt], mask[:, :n_prompt], torch.arange(n_prompt).unsqueeze(0).repeat(2, 1)
+    all_t, all_m = cur_t, cur_m
+    frames_b2 = []
+    for step in range(6):
+        torch.manual_seed(2000 + step)
+        with torch.no_grad():
+            f_ref = model.generate_frame(cur_t, cur_m, cur_p, 0.9, 10)
+        torch.manual_seed(2000 + step)
+        qs = [torch.empty(2, TINY.audio_vocab).exponential_(1) for _ in range(K)]
+        with torch.no_grad():
+            f_or = O.generate_frame(params, TINY, all_t, all_m, 0.9, 10, qs)
+        assert torch.equal(f_ref, f_or), (step, f_ref, f_or)
+        frames_b2.append(f_ref.tolist())
+        nxt = torch.cat([f_ref.long(), torch.zeros(2, 1, dtype=torch.long)], dim=1).unsqueeze(1)
+        nm = torch.cat([torch.ones(2, K, dtype=torch.bool), torch.zeros(2, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
+        all_t, all_m = torch.cat([all_t, nxt], 1), torch.cat([all_m, nm], 1)
+        cur_t, cur_m, cur_p = nxt, nm, cur_p[:, -1:] + 1
+    meta["generate_frames_b2"] = frames_b2
 
     # -- 2. HF cross-check of the stack arithmetic -----------------------------------------------------
     meta["hf_crosscheck"] = hf_crosscheck(params)
@@ -247,10 +267,24 @@ def main():
     for k in ["backbone.layers.0.attn.q_proj.weight", "backbone.layers.1.mlp.w2.weight", "backbone.norm.scale",
               "decoder.layers.0.attn.k_proj.weight", "decoder.layers.1.mlp.w1.weight", "projection.weight",
               "codebook0_head.weight", "audio_head", "text_embeddings.weight", "audio_embeddings.weight"]:
-        gsel[k] = ptrain[k].grad
+        gsel[k] = ptrain[k].grad.clone()
     meta["train_step"] = {"total": float(total), "semantic": float(det["semantic_loss"]),
                           "acoustic": float(det["acoustic_loss"]), "rows_stride": 3,
                           "grad_norm": float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ptrain.values())))}
+
+    # -- 4b. the parameters AFTER that step: global-norm clip to 1.0, then torch's own AdamW with the four
+    # learning-rate groups of reference trainer.py:143-159 (backbone x0.1, decoder x1.0, embeddings x0.5, other x1; wd 0.01)
+    lr = 1e-3
+    groups = {"backbone": [], "decoder": [], "embeddings": [], "other": []}
+    for k, v in ptrain.items():
+        groups["backbone" if "backbone" in k else "decoder" if "decoder" in k else "embeddings" if "embeddings" in k else "other"].append(v)
+    torch.nn.utils.clip_grad_norm_(list(ptrain.values()), 1.0)
+    opt = torch.optim.AdamW([{"params": groups["backbone"], "lr": lr * 0.1}, {"params": groups["decoder"], "lr": lr * 1.0},
+                             {"params": groups["embeddings"], "lr": lr * 0.5}, {"params": groups["other"], "lr": lr}],
+                            lr=lr, weight_decay=0.01)
+    opt.step()
+    post = {k: ptrain[k].detach().clone() for k in gsel}
+    meta["train_step"]["post_adamw"] = {"lr": lr, "multipliers": [0.1, 1.0, 0.5, 1.0], "weight_decay": 0.01, "max_grad_norm": 1.0}
 
     # -- 5. RVQ ----------------------------------------------------------------------------------------------
     g = torch.Generator().manual_seed(21)
@@ -268,6 +302,7 @@ def main():
         rvq_codes=codes.numpy(), rvq_decode_head=dec[:4].numpy(),
         **{"grad::" + k: v.detach().numpy()[..., :64].copy() if v.dim() > 1 else v.detach().numpy()
            for k, v in gsel.items()},
+        **{"post::" + k: v.numpy()[..., :64].copy() if v.dim() > 1 else v.numpy() for k, v in post.items()},
     )
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -199,6 +199,87 @@ def test_gradsync_two_ranks_gloo():
     assert all(ok for _, ok, _ in res), res
 
 
+def _dp_helpers_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
+    from types import SimpleNamespace
+    from csm.training.dp import GradSync
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    # replicas that start different are made equal by the broadcast, and the checksum test sees both states
+    m = SimpleNamespace(arena=(torch.arange(4096, dtype=torch.float32) * (rank + 1)).to(torch.bfloat16), lora=None)
+    try:
+        GradSync.assert_replicas_equal(m)
+        out["diverged_detected"] = False
+    except RuntimeError:
+        out["diverged_detected"] = True
+    GradSync.broadcast_parameters(m)
+    GradSync.assert_replicas_equal(m)
+    out["after_broadcast"] = torch.equal(m.arena, torch.arange(4096, dtype=torch.float32).to(torch.bfloat16))
+    # logged scalars are averaged over the ranks
+    out["mean"] = GradSync.mean_scalar(float(rank + 1))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_dp_replica_helpers_two_ranks_gloo(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_helpers_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for r in (0, 1):
+        assert res[r]["diverged_detected"] and res[r]["after_broadcast"] and res[r]["mean"] == 1.5, res
+
+
+def test_checkpoint_is_written_atomically(tmp_path):
+    """save_checkpoint goes through a temporary file + rename and leaves no partial file behind."""
+    from types import SimpleNamespace
+    from csm.training.utils import save_checkpoint
+    model = SimpleNamespace(state_dict=lambda: {"w": torch.ones(3)})
+    path = save_checkpoint(model, None, 1, 7, 0.5, str(tmp_path), "ck")
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["ck_epoch1_step7.pt", "ck_latest.pt"] and os.path.basename(path) == "ck_epoch1_step7.pt"
+    assert torch.load(path, weights_only=False)["global_step"] == 7
+
+
+def test_optimizer_state_groups_match_by_name():
+    """FusedAdamW.load_state_dict refuses a state saved for other parameter groups (freeze flags changed)."""
+    from csm.training.optim import FusedAdamW
+    opt = FusedAdamW.__new__(FusedAdamW)
+    opt.param_groups = [dict(name="decoder", lr=1.0, weight_decay=0.0, offset=0, numel=4), dict(name="other", lr=2.0, weight_decay=0.0, offset=4, numel=4)]
+    opt.state = {"decoder": {"m": torch.zeros(4)}, "other": {"m": torch.zeros(4)}}
+    good = {"step": 3, "groups": [dict(name="other", lr=0.2, weight_decay=0.1, offset=4, numel=4), dict(name="decoder", lr=0.1, weight_decay=0.1, offset=0, numel=4)],
+            "state": {"decoder": {"m": torch.ones(4)}, "other": {"m": torch.full((4,), 2.0)}}}
+    opt.load_state_dict(good)      # saved in another ORDER: still lands on the right groups
+    assert opt.step_count == 3 and opt.param_groups[0]["lr"] == 0.1 and opt.param_groups[1]["lr"] == 0.2
+    assert float(opt.state["other"]["m"][0]) == 2.0
+    bad = dict(good, groups=[dict(name="backbone", lr=0.2, weight_decay=0.1, offset=4, numel=4), good["groups"][1]])
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
+
+
+def test_rope_table_all_positions_matches_fixture():
+    """Llama-3 scaled RoPE tables for positions 0..2047 at both head dims: the oracle's table (hash pinned by the fixture,
+    which also records its distance to the Hugging Face rotary embedding) and the table the HIP path is fed."""
+    import hashlib
+    from csm.models.model import llama3_rope_table
+    z = np.load(os.path.join(GOLD, "golden_full_layer.npz"))
+    meta = json.load(open(os.path.join(GOLD, "golden_full_layer_meta.json")))
+    rows = [0, 1, 2, 63, 64, 511, 1024, 2047]
+    for hd in (64, 128):
+        tab = O.rope_table(2048, hd)
+        assert hashlib.sha256(tab.contiguous().numpy().tobytes()).hexdigest()[:16] == meta[f"rope_hd{hd}"]["sha"]
+        assert meta[f"rope_hd{hd}"]["max_abs_diff_vs_hf"] < 2e-3
+        assert np.array_equal(tab[rows].numpy(), z[f"rope_hd{hd}::rows"])
+        prod = llama3_rope_table(2048, hd, 500000.0, 32.0)
+        assert prod.shape == tab.shape and float((prod - tab).abs().max()) <= 1e-6
+
+
 def test_gradsync_bucket_plan_for_model():
     from csm.models.model import Model, ModelArgs
     from csm.training.dp import GradSync

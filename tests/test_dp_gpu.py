@@ -114,3 +114,81 @@ def test_two_rank_dp_matches_single_process(dev, mode):
     assert err <= 2e-3 * ref.abs().max().item() + 4.2e-3, f"DP(2) vs single-process on the same 4 micro-batches: max abs diff {err}"
     frac = ((s0 - ref).abs() > 1e-3).float().mean().item()
     assert frac < 0.02, f"{frac:.3%} of the weights differ by more than one Adam step"
+
+
+def _train_worker(rank, world, port, q, outdir, cap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    if cap:
+        os.environ["CSM_DP_TEXT_ROWS_CAP"] = str(cap)
+    for p in (ROOT, os.path.join(ROOT, "csm-train-pytorch_amd")):
+        sys.path.insert(0, p)
+    from oracle import csm_oracle as O
+    from csm.data import SyntheticCSMDataset
+    from csm.models.model import Model, ModelArgs
+    from csm.training.trainer import CSMTrainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = O.tiny_cfg()
+    # DIFFERENT seeds per rank: prepare_optimizer must broadcast rank 0's parameters
+    m = Model(ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", cfg.text_vocab, cfg.audio_vocab, cfg.n_codebooks), device="cuda:0", seed=3 + rank)
+    tr = CSMTrainer("", outdir, device="cuda:0")
+    tr.model = m
+    tr.num_workers = 0
+    tr.prepare_optimizer()
+    ds = SyntheticCSMDataset(8, 24, cfg.text_vocab, cfg.audio_vocab, cfg.n_codebooks, seed=7)
+    res = {}
+    if cap:
+        try:
+            for step in range(3):
+                tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=50 + step + 10 * rank)
+                tr.train_step({"input_tokens": tokens, "input_masks": mask, "target_audio_tokens": targets}, 1, True, 1.0)
+                torch.cuda.synchronize()
+            res["raised"] = False
+        except RuntimeError as e:
+            res["raised"] = "CSM_DP_TEXT_ROWS_CAP" in str(e)
+    else:
+        tr.grad_sync.timing = True
+        tr.train(ds, batch_size=2, accumulation_steps=1, epochs=1, save_every=1)
+        res["exposed"] = tr.grad_sync.exposed_comm_ms()
+        res["state"] = m.arena.float().cpu().numpy()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_loop_one_writer(dev, tmp_path):
+    """CSMTrainer.train under DP: replicas start from rank 0's weights whatever their own seed was, only rank 0 writes
+    checkpoints and log lines (both ranks share ONE output directory), nothing half-written stays behind."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + os.getpid() % 1000
+    out = str(tmp_path / "run")
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, out, 0)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert (res[0]["state"] == res[1]["state"]).all(), "replicas diverged (initial broadcast missing?)"
+    files = sorted(os.listdir(out))
+    assert not [f for f in files if f.endswith(".tmp")], files
+    # 8 items / (2 ranks x batch 2) = 2 optimiser steps: periodic x2, epoch, final (+ their _latest twins)
+    assert {"checkpoint_epoch1_step1.pt", "checkpoint_epoch1_step2.pt", "checkpoint_latest.pt", "epoch_1_epoch1_step2.pt", "final_epoch1_step2.pt"} <= set(files), files
+    log = open(os.path.join(out, "training.log")).read()
+    assert log.count("Training completed") == 1 and log.count("Epoch 1 completed") == 1, log
+    assert len(res[0]["exposed"]) == 2 and all(x >= 0 for x in res[0]["exposed"])
+
+
+def test_text_row_exchange_overflow_is_reported(dev, tmp_path):
+    """More distinct text rows in a step than the exchange's fixed capacity: the device-side flag reaches the host one
+    step later and training stops with a clear message (no silent gradient loss, no per-step host sync)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30900 + os.getpid() % 1000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, str(tmp_path / f"o{r}"), 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res[0]["raised"] is True and res[1]["raised"] is True, res

@@ -137,6 +137,52 @@ def test_train_step_full(dev):
         assert torch.equal(dict(m.named_parameters())[k].detach().float().cpu(), masters[k].to(BF).float().cpu()), k
 
 
+def test_post_adamw_parameters_match_fixture(dev):
+    """the parameters AFTER one CSMTrainer step (clip 1.0, four learning-rate groups x0.1 / x1 / x0.5 / x1,
+    weight decay 0.01) against values produced by torch's own clip_grad_norm_ + AdamW on the oracle's fp32 gradients."""
+    from csm.training.trainer import CSMTrainer
+    m, p32, pq = tiny_model(dev)
+    m.acoustic_mode = "all"
+    z = np.load(os.path.join(GOLD, "golden_small.npz"))
+    meta = json.load(open(os.path.join(GOLD, "golden_meta.json")))
+    cfgp = meta["train_step"]["post_adamw"]
+    tokens, mask, targets = (torch.from_numpy(z[k]) for k in ("tokens", "mask", "targets"))
+    B, S = tokens.shape[:2]
+    rows = torch.arange(0, B * (S - 1), meta["train_step"]["rows_stride"])
+    tr = CSMTrainer("", "/tmp/csm_post_adamw", device=str(dev), learning_rate=cfgp["lr"], backbone_lr_multiplier=cfgp["multipliers"][0],
+                    decoder_lr_multiplier=cfgp["multipliers"][1], embedding_lr_multiplier=cfgp["multipliers"][2], weight_decay=cfgp["weight_decay"])
+    tr.logger.setLevel(40)
+    tr.model = m
+    tr.prepare_optimizer()
+    from csm.training.utils import compute_loss
+    total, _ = compute_loss(m, tokens, mask, targets, 100.0, 1.0, acoustic_rows=rows)
+    total.backward()
+    tr.optimizer.clip_grad_norm(cfgp["max_grad_norm"])
+    tr.optimizer.step()
+    masters = dict(tr.optimizer.named_master())
+    checked = 0
+    for key in z.files:
+        if not key.startswith("post::"):
+            continue
+        k = key[6:]
+        ref = torch.from_numpy(z[key])
+        got = masters[k].float().cpu()
+        got = got[..., :64] if got.dim() > 1 else got
+        start = p32[k][..., :64] if p32[k].dim() > 1 else p32[k]
+        gref = torch.from_numpy(z["grad::" + k])
+        upd, upd_ref = got - start, ref - start
+        # step 1 of Adam moves a weight by ~lr * sign(g): compare where the gradient is clearly non-zero (elsewhere eps and
+        # the bf16 noise of the HIP gradient decide the sign)
+        big = gref.abs() > 0.2 * gref.abs().max()
+        assert big.any(), k
+        lr_k = cfgp["lr"] * (cfgp["multipliers"][0] if "backbone" in k else cfgp["multipliers"][1] if "decoder" in k else
+                             cfgp["multipliers"][2] if "embeddings" in k else cfgp["multipliers"][3])
+        assert (upd[big] - upd_ref[big]).abs().max().item() < 0.1 * lr_k, (k, (upd[big] - upd_ref[big]).abs().max().item(), lr_k)
+        assert (upd_ref[big].abs() > 0.5 * lr_k).all(), k      # the fixture really moved by about one learning rate
+        checked += 1
+    assert checked >= 8
+
+
 def test_grad_accumulation_and_freeze(dev):
     from csm.training.utils import compute_loss
     m, _, _ = tiny_model(dev)
@@ -248,6 +294,65 @@ def test_lora_step(dev):
     assert rel(after, before) < 2e-3
 
 
+def test_lora_rank4_mlp_adapters_and_trainer_step(dev, tmp_path):
+    """Row a9 + the r = 4 case the reference documents: ``CSMLoRATrainer.train_step`` (loss -> gradients of the LoRA
+    parameters only -> clip g * max_norm / (||g|| + 1e-6) when ||g|| > max_norm -> Adam, no weight decay; reference
+    lora_trainer.py:374-457, mlx_trainer.py:688-731) against the oracle, with rank 4 (stored padded to 8) and adapters on
+    q / v / w1 / w3 - the w1 / w3 pair goes through the SwiGLU epilogue's residual port."""
+    from csm.training.lora_trainer import CSMLoRATrainer
+    from csm.data import SyntheticCSMDataset
+    m, p32, pq = tiny_model(dev)
+    m.acoustic_mode = "all"
+    lr = 1e-3
+    tr = CSMLoRATrainer("", str(tmp_path), learning_rate=lr, lora_r=4, lora_alpha=8.0,
+                        target_modules=["q_proj", "v_proj", "w1", "w3"], device=str(dev), model=m)
+    tr.logger.setLevel(40)
+    lo = m.lora
+    assert lo.r == 4 and lo.r_pad == 8
+    with torch.no_grad():
+        g = torch.Generator(device=dev).manual_seed(12)
+        for ad in lo.adapters.values():
+            ad.B[:, :4].copy_((torch.randn(ad.B.shape[0], 4, generator=g, device=dev) * 0.05).to(BF))
+    names = dict(lo.named_tensors())
+    assert all(v.shape[0] == 4 for k, v in names.items() if k.endswith("lora_A")) and all(v.shape[1] == 4 for k, v in names.items() if k.endswith("lora_B"))
+    before = {k: v.detach().float().cpu().clone() for k, v in names.items()}
+    tr.prepare_optimizer()
+    tr.max_grad_norm = 1.0
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=16)
+    loss = tr.train_step({"input_tokens": tokens.numpy(), "input_masks": mask.numpy(), "target_audio_tokens": targets.numpy()})
+    assert loss.dim() == 0
+    # oracle: same loss, same clip rule, Adam without decay
+    lora = {k: v.clone().requires_grad_(True) for k, v in before.items()}
+    rt, _ = O.compute_loss(pq, TINY, tokens, mask, targets, 100.0, 1.0, acoustic_rows=None, lora=lora, lora_scaling=2.0)
+    rt.backward()
+    assert rel(loss, rt) < 1e-3, (float(loss), float(rt))
+    grads = {k: v.grad.clone() for k, v in lora.items()}
+    norm = float(torch.sqrt(sum((gv.double() ** 2).sum() for gv in grads.values())))
+    assert norm > 1.0, "the clip must be live in this test"
+    after = {k: v.detach().float().cpu() for k, v in lo.named_tensors()}
+    checked = 0
+    for k, gv in grads.items():
+        gv = gv * (1.0 / (norm + 1e-6))
+        ref = before[k].clone()
+        O.adamw_step(ref, gv, torch.zeros_like(ref), torch.zeros_like(ref), 1, lr, weight_decay=0.0)
+        big = gv.abs() > 0.2 * gv.abs().max()
+        # bf16 working copy of the updated parameter: one learning rate of movement, compared at bf16 resolution
+        tol = 0.15 * lr + 2.0 ** -8 * ref[big].abs().max().item()
+        assert ((after[k] - before[k])[big] - (ref - before[k])[big]).abs().max().item() <= tol, k
+        checked += 1
+    assert checked == 2 * len(lo.adapters)
+    # the padding of the rank-4 adapters (rows 4..7 of A, columns 4..7 of B) is still exactly zero after the step
+    for ad in lo.adapters.values():
+        assert float(ad.A[4:].abs().max()) == 0.0 and float(ad.B[:, 4:].abs().max()) == 0.0 and float(ad.gA[4:].abs().max()) == 0.0
+    # train() keeps the reference's return contract: best_loss, inf when no validation ran (mlx_trainer.py:733-876)
+    ds = SyntheticCSMDataset(4, 24, TINY.text_vocab, TINY.audio_vocab, TINY.n_codebooks, seed=2)
+    assert tr.train(ds, batch_size=2, epochs=1, save_every=1) == float("inf")
+    assert os.path.exists(os.path.join(str(tmp_path), "checkpoint_step_2.safetensors"))
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(str(tmp_path), "checkpoint_step_2.safetensors"))
+    assert all(tuple(sd[k].shape) == tuple(v.shape) for k, v in lo.named_tensors())
+
+
 def test_lora_dropout_and_bias_step(dev):
     """lora_dropout > 0 and lora_use_bias (reference lora.py:85-102): the oracle is given the very masks the HIP path
     drew (regenerated from each adapter's seed), so loss and every adapter gradient can be compared exactly as above."""
@@ -297,26 +402,36 @@ def test_lora_dropout_and_bias_step(dev):
     assert float(a1) == float(a2)
 
 
-def test_generate_frame_matches_reference_fixture(dev):
-    """Frames sampled by the REFERENCE's generate_frame (fp32, stand-in stacks) for fixed noise: indices bit-exact."""
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_generate_frame_matches_reference_fixture(dev, use_graph):
+    """Frames sampled by the REFERENCE's generate_frame (fp32, stand-in stacks) for fixed noise: indices bit-exact, for
+    8 frames of one prompt and 6 frames of a batch of two.  With ``use_graph`` (the default of ``generate()``) frame 0 is
+    the prefill, frame 1 the eager warm-up, and every later frame a REPLAY of the captured HIP graph whose Exp(1) noise
+    was written into the persistent device buffer before the replay."""
     m, p32, pq = tiny_model(dev)
     meta = json.load(open(os.path.join(GOLD, "golden_meta.json")))
     z = np.load(os.path.join(GOLD, "golden_small.npz"))
     tokens, mask = torch.from_numpy(z["tokens"]), torch.from_numpy(z["mask"])
     K = TINY.n_codebooks
-    m.setup_caches(1)
+    m.use_hip_graph = use_graph
     n_prompt = 9
-    cur_t, cur_m, cur_p = tokens[:1, :n_prompt], mask[:1, :n_prompt], torch.arange(n_prompt).unsqueeze(0)
-    got = []
-    for step in range(3):
-        torch.manual_seed(1000 + step)
-        qs = [torch.empty(1, TINY.audio_vocab).exponential_(1) for _ in range(K)]
-        f = m.generate_frame(cur_t, cur_m, cur_p, 0.9, 10, noise=qs).cpu()
-        got.append(f[0].tolist())
-        cur_t = torch.cat([f.long(), torch.zeros(1, 1, dtype=torch.long)], dim=1).unsqueeze(1)
-        cur_m = torch.cat([torch.ones(1, K, dtype=torch.bool), torch.zeros(1, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
-        cur_p = cur_p[:, -1:] + 1
-    assert got == meta["generate_frames"], (got, meta["generate_frames"])
+    for B, seed0, want in ((1, 1000, meta["generate_frames"]), (2, 2000, meta["generate_frames_b2"])):
+        m.setup_caches(B)
+        m.reset_caches()
+        cur_t, cur_m, cur_p = tokens[:B, :n_prompt], mask[:B, :n_prompt], torch.arange(n_prompt).unsqueeze(0).repeat(B, 1)
+        got = []
+        for step in range(len(want)):
+            torch.manual_seed(seed0 + step)
+            qs = [torch.empty(B, TINY.audio_vocab).exponential_(1) for _ in range(K)]
+            f = m.generate_frame(cur_t, cur_m, cur_p, 0.9, 10, noise=qs).cpu()
+            got.append(f[0].tolist() if B == 1 else f.tolist())
+            cur_t = torch.cat([f.long(), torch.zeros(B, 1, dtype=torch.long)], dim=1).unsqueeze(1)
+            cur_m = torch.cat([torch.ones(B, K, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
+            cur_p = cur_p[:, -1:] + 1
+        assert got == want, (B, use_graph, got, want)
+        if use_graph:
+            assert m._decode_state.graph is not None, "frames >= 2 must have gone through the captured graph"
+    m.use_hip_graph = True
 
 
 def test_generate_kv_cache_vs_recompute_and_graph(dev):
@@ -352,27 +467,39 @@ def test_generate_kv_cache_vs_recompute_and_graph(dev):
     agree = (kv == rc).float().mean().item()
     assert agree >= 0.9, f"KV-cache and recompute paths agree on only {agree:.1%} of the sampled codes"
     assert torch.equal(kv[0], rc[0]), "the prefill frame goes through the same kernels in both paths"
-    # graph replay == eager decode, with torch's own generator seeded identically
+    # graph replay == eager decode, frame for frame, given the same noise through the persistent buffer
     outs = []
     for use_graph in (False, True):
         m.use_hip_graph = use_graph
         m.setup_caches(2)
         m.reset_caches()
-        torch.manual_seed(1234)
-        torch.cuda.manual_seed(1234)
         cur_t, cur_m, cur_p = tokens[:, :11], mask[:, :11], torch.arange(11).unsqueeze(0).repeat(2, 1)
         frames = []
-        for step in range(6):
-            f = m.generate_frame(cur_t, cur_m, cur_p, 0.8, 12).cpu()
+        for step in range(8):
+            f = m.generate_frame(cur_t, cur_m, cur_p, 0.8, 12, noise=noise(step)).cpu()
             frames.append(f)
             cur_t = torch.cat([f.long(), torch.zeros(2, 1, dtype=torch.long)], dim=1).unsqueeze(1)
             cur_m = torch.cat([torch.ones(2, K, dtype=torch.bool), torch.zeros(2, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
             cur_p = cur_p[:, -1:] + 1
         outs.append(torch.stack(frames))
     m.use_hip_graph = True
-    assert outs[0].shape == outs[1].shape == (6, 2, K)
-    assert torch.equal(outs[0][:2], outs[1][:2]), "prefill + eager warm-up frame are identical code paths"
-    assert int(outs[1].min()) >= 0 and int(outs[1].max()) < TINY.audio_vocab
+    assert torch.equal(outs[0], outs[1]), "graph replay must reproduce the eager KV-cache frames bit for bit"
+    assert torch.equal(outs[0], kv), "and both equal the first run"
+    # fresh draws (noise=None): the replayed graph must still see NEW noise every frame (the buffer is refilled outside it)
+    m.setup_caches(2)
+    m.reset_caches()
+    torch.manual_seed(7)
+    torch.cuda.manual_seed(7)
+    cur_t, cur_m, cur_p = tokens[:, :11], mask[:, :11], torch.arange(11).unsqueeze(0).repeat(2, 1)
+    seen = []
+    for step in range(6):
+        f = m.generate_frame(cur_t, cur_m, cur_p, 1.5, 50).cpu()
+        seen.append(m._decode_state.noise_buf[0, 0, :8].cpu().clone())
+        cur_t = torch.cat([f.long(), torch.zeros(2, 1, dtype=torch.long)], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones(2, K, dtype=torch.bool), torch.zeros(2, 1, dtype=torch.bool)], dim=1).unsqueeze(1)
+        cur_p = cur_p[:, -1:] + 1
+        assert int(f.min()) >= 0 and int(f.max()) < TINY.audio_vocab
+    assert all(not torch.equal(seen[i], seen[i + 1]) for i in range(5)), "every frame needs its own noise"
 
 
 def test_decode_kernels_vs_oracle(dev):
@@ -568,3 +695,101 @@ def test_full_size_model_properties(dev):
         to, _ = O.compute_loss(params, O.csm_1b_cfg(), short["input_tokens"], short["input_masks"], short["target_audio_tokens"],
                                acoustic_rows="off")
     assert rel(tg, to) < 1e-3, (float(tg), float(to))
+
+
+def test_full_size_acoustic_and_adamw_vs_oracle(dev):
+    """CSM-1B (real widths, 16 + 4 layers) at a sequence short enough for the CPU oracle: semantic AND acoustic loss terms,
+    the global gradient norm, and one clipped AdamW step with the reference's four learning-rate groups, against the
+    oracle run on the same weights (bf16 values widened to fp32)."""
+    from csm.data import SyntheticCSMDataset, collate_variable_length
+    from csm.models.model import Model
+    from csm.training.trainer import CSMTrainer, csm_1b_args
+    from csm.training.utils import compute_loss
+    m = Model(csm_1b_args(), device=dev, seed=0)
+    m.acoustic_mode = "all"
+    S = 64
+    batch = collate_variable_length([SyntheticCSMDataset(1, S, seed=91)[0]])
+    rows = torch.tensor([3, 17, 29, 30, 41, 52, 60, 62])
+    lr = 1e-3
+    tr = CSMTrainer("", "/tmp/csm_full_adamw", device=str(dev), learning_rate=lr)
+    tr.logger.setLevel(40)
+    tr.model = m
+    params = {k: v.float().cpu() for k, v in m._views(m.arena).items()}          # before the step
+    tr.prepare_optimizer()
+    total, det = compute_loss(m, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"], 100.0, 1.0, acoustic_rows=rows)
+    total.backward()
+    norm = tr.optimizer.clip_grad_norm(1.0)
+    tr.optimizer.step()
+    masters = dict(tr.optimizer.named_master())
+    # ---- oracle
+    cfg = O.csm_1b_cfg()
+    pt = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    rt, rd = O.compute_loss(pt, cfg, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"], 100.0, 1.0, acoustic_rows=rows)
+    rt.backward()
+    assert rel(det["semantic_loss"], rd["semantic_loss"]) < 1e-3, (float(det["semantic_loss"]), float(rd["semantic_loss"]))
+    assert rel(det["acoustic_loss"], rd["acoustic_loss"]) < 1e-3, (float(det["acoustic_loss"]), float(rd["acoustic_loss"]))
+    assert rel(total, rt) < 1e-3
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in pt.values())))
+    assert rel(norm, gn) < 2e-2, (float(norm), gn)
+    coef = min(1.0, 1.0 / (gn + 1e-6))
+    mult = {"backbone": 0.1, "decoder": 1.0, "embeddings": 0.5, "other": 1.0}
+    for k in ["backbone.layers.0.attn.q_proj.weight", "backbone.layers.7.mlp.w1.weight", "backbone.layers.15.mlp.w2.weight", "backbone.norm.scale",
+              "decoder.layers.0.attn.v_proj.weight", "decoder.layers.3.mlp.w3.weight", "projection.weight", "codebook0_head.weight",
+              "audio_head", "audio_embeddings.weight"]:
+        grp = "backbone" if "backbone" in k else "decoder" if "decoder" in k else "embeddings" if "embeddings" in k else "other"
+        g = pt[k].grad * coef
+        ref = params[k].clone()
+        O.adamw_step(ref, g, torch.zeros_like(ref), torch.zeros_like(ref), 1, lr * mult[grp], weight_decay=0.01)
+        upd, upd_ref = masters[k].float().cpu() - params[k], ref - params[k]
+        big = g.abs() > 0.2 * g.abs().max()
+        assert big.any(), k
+        err = (upd[big] - upd_ref[big]).abs().max().item()
+        assert err < 0.1 * lr * mult[grp], (k, err)
+        assert upd_ref[big].abs().min().item() > 0.5 * lr * mult[grp], k
+
+
+def test_full_size_lora_config3_properties(dev):
+    """BASELINE config 3 at full size (CSM-1B, LoRA r=8 on q_proj / v_proj, S=2048, B=8), where only size-independent
+    properties can be checked: fresh adapters (B = 0) leave the loss bit-identical to the bare model's, the base weights
+    receive no gradient, dA is exactly 0 while dB is not (the chain rule through B = 0), the step is bit-reproducible,
+    and merging the trained adapters reproduces the adapted loss."""
+    from csm.data import SyntheticCSMDataset, collate_variable_length
+    from csm.models.model import Model
+    from csm.training.lora import apply_lora_to_model, merge_lora_weights
+    from csm.training.optim import FusedAdamW
+    from csm.training.trainer import csm_1b_args
+    from csm.training.utils import compute_loss
+    m = Model(csm_1b_args(), device=dev, seed=0)
+    m.acoustic_mode = "off"
+    ds = SyntheticCSMDataset(8, 2048, seed=55)
+    batch = {k: v.to(dev) for k, v in collate_variable_length([ds[i] for i in range(8)]).items()}
+    args = (batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"])
+    with torch.no_grad():
+        bare, _ = compute_loss(m, *args)
+    apply_lora_to_model(m, r=8, alpha=16.0, target_modules=["q_proj", "v_proj"], seed=1)
+    assert m.lora.num_params() == 958464                       # SURVEY 8a, row a7
+    opt = FusedAdamW(m, {}, lora_lr=1e-3)
+
+    def step():
+        m.lora.grad_arena.zero_()
+        total, _ = compute_loss(m, *args)
+        total.backward()
+        return float(total), m.lora.grad_arena.clone()
+
+    t1, g1 = step()
+    t2, g2 = step()
+    assert t1 == float(bare), "adapters with B = 0 must not change a single bit of the loss"
+    assert t1 == t2 and torch.equal(g1, g2), "bit-reproducible"
+    assert m.grad_arena is None or float(m.grad_arena.abs().max()) == 0.0, "base weights are frozen"
+    for ad in m.lora.adapters.values():
+        assert float(ad.gA.abs().max()) == 0.0, "dA = (dy B)^T x = 0 while B = 0"
+    # (loss mode A: only the backbone runs, so only its adapters see a gradient)
+    assert all(float(ad.gB.float().abs().max()) > 0 for (prefix, _, _), ad in m.lora.adapters.items() if prefix == "backbone")
+    opt.step(zero_grad=True)
+    with torch.no_grad():
+        adapted, _ = compute_loss(m, *args)
+        assert float(adapted) != float(bare)
+        merge_lora_weights(m)
+        m.lora = None
+        merged, _ = compute_loss(m, *args)
+    assert rel(merged, adapted) < 2e-3, (float(merged), float(adapted))

@@ -42,9 +42,7 @@ class RvqOnlyCodec:
         return (out @ self.proj.t()).reshape(1, 1, -1)
 
 
-def main():
-    dev = "cuda:0"
-    model = Model(csm_1b_args(), device=dev, seed=0)
+def make_codec(dev):
     if os.environ.get("GEN_CODEC", "mimi") == "mimi":
         from transformers import MimiConfig, MimiModel
         from csm.codec import MimiCodec
@@ -54,9 +52,39 @@ def main():
             for name, buf in hf.named_buffers():
                 if name.endswith("embed_sum"):
                     buf.copy_(torch.randn(buf.shape))
-        codec = MimiCodec(hf.state_dict(), device=dev)
-    else:
-        codec = RvqOnlyCodec(dev)
+        return MimiCodec(hf.state_dict(), device=dev)
+    return RvqOnlyCodec(dev)
+
+
+def run(model, frames=125, repeats=2):
+    """BASELINE config 5 on an existing model (bench.py's extra leg): 5 s of context audio tokenised by Mimi, ``frames`` AR
+    frames, Mimi decode.  Returns the best of ``repeats`` timed runs after one short warm-up."""
+    dev = model.device
+    if not model.caches_are_enabled():
+        model.setup_caches(1)
+    gen = Generator(model, text_tokenizer=ByteTokenizer(), audio_tokenizer=make_codec(dev))
+    ctx = [Segment(0, "hello there", torch.randn(5 * 24000, device=dev) * 0.1)]
+    text = "the quick brown fox jumps over the lazy dog"
+    gen.generate(text, 1, ctx, max_audio_length_ms=80 * 5)                  # warm-up: lazy attributes, allocator, graph capture
+    best = None
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        audio = gen.generate(text, 1, ctx, max_audio_length_ms=80 * frames)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        nfr = audio.numel() / 1920
+        if best is None or dt / max(nfr, 1) < best[0] / max(best[1], 1):
+            best = (dt, nfr)
+    dt, nfr = best
+    return {"frames": nfr, "seconds": round(dt, 4), "frames_per_s": round(nfr / dt, 1), "ms_per_frame": round(dt / max(nfr, 1) * 1e3, 3),
+            "x_real_time": round(nfr * 0.08 / dt, 2), "includes": "Mimi encode of the context + prefill + decode frames + Mimi decode"}
+
+
+def main():
+    dev = "cuda:0"
+    model = Model(csm_1b_args(), device=dev, seed=0)
+    codec = make_codec(dev)
     gen = Generator(model, text_tokenizer=ByteTokenizer(), audio_tokenizer=codec)
     ctx = [Segment(0, "hello there", torch.randn(5 * 24000, device=dev) * 0.1)]        # 5 s of context audio to tokenise
     frames = int(os.environ.get("GEN_FRAMES", 125))
