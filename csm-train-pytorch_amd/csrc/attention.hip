@@ -589,8 +589,12 @@ static void launch_dkv(const void* qkv, const void* dout, const float* lse, cons
 }
 
 static int g_attn_qt_fwd = 2, g_attn_qt_bwd = 1;   // query tiles per wave of the head_dim-64 forward / dQ kernels
-static int g_attn_gen2 = 1;                          // head_dim 64: second-generation kernels of attention64.hip (bit0 fwd, bit1 bwd)
+static int g_attn_gen2 = 3;                          // head_dim 64: second-generation kernels of attention64.hip (bit0 fwd, bit1 bwd)
 int csm_attn64_fwd_launch(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, hipStream_t stream);
+int csm_attn64_dkv_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
+                          int KV, const float* rope, hipStream_t stream);
+int csm_attn64_dq_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int S,
+                         int H, int KV, const float* rope, hipStream_t stream);
 extern "C" int csm_set_attn_variant(int v) {
     // 0 restores the defaults.  Otherwise an experiment word: bits 0..1 / 2..3 query tiles per wave of the head_dim-64
     // forward / dQ kernel (1 | 2; 0 = 1); bits 4..5 dK/dV work order (0 plain, 1 / 2 complementary pairing, 3 heaviest key blocks first);
@@ -633,10 +637,12 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     void* o = const_cast<void*>(out);
     float* l = const_cast<float*>(lse);
     if (HD == 64) {
-        if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        if (g_attn_gen2 & 2) csm_attn64_dq_launch(qkv, out, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
+        else if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         else launch_q<64, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
-        if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        if (g_attn_gen2 & 2) csm_attn64_dkv_launch(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
+        else if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
     } else {
         launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);

@@ -344,6 +344,453 @@ __global__ __launch_bounds__(256, 3) void attn64_fwd_kernel(const bf16_t* __rest
     }
 }
 
+// Backward of torchtune's interleaved-pair RoPE on two adjacent pairs (x0,x1), (x2,x3) of position p (see attention.hip)
+__device__ __forceinline__ void unrope2(const float* __restrict__ table, int p, int hd, int pair, float& g0, float& g1, float& g2,
+                                        float& g3) {
+    const float4 t = *reinterpret_cast<const float4*>(table + ((size_t)p * (hd >> 1) + pair) * 2);   // c0, s0, c1, s1
+    const float a0 = g0 * t.x + g1 * t.y, a1 = g1 * t.x - g0 * t.y;
+    const float a2 = g2 * t.z + g3 * t.w, a3 = g3 * t.z - g2 * t.w;
+    g0 = a0; g1 = a1; g2 = a2; g3 = a3;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dQ: the forward's skeleton (128 queries of one (b, h) per workgroup, 32 per wave on the lanes, 32-key tiles from the
+// K / V ring) with three products per tile: S^T = K Q^T, dP^T = V dO^T (its accumulators START at -delta, so
+// dS = P o dP needs no subtraction), dQ^T += K^T dS^T (K^T by transposed reads of the same K image; dS^T straight from
+// the accumulators).  P = exp2(c S - lse) needs no running max.  Also computes delta = rowsum(dO o O) from the same row
+// fragments and publishes it for the dK/dV kernel, and applies the RoPE backward in the epilogue (rope != null).
+__global__ __launch_bounds__(256, 2) void attn64_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S, int H, int KV,
+                                                           float scale, const float* __restrict__ rope) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rep = H / KV;
+    const int nqblk = (S + 127) / 128;
+    int pair, hh, qb;
+    work_item(nqblk, rep, pair, hh, qb);
+    const int kvh = pair % KV, b = pair / KV;
+    const int hq = kvh * rep + hh;
+    const int ld = (H + 2 * KV) * 64, ldo = H * 64;
+    const bf16_t* Qp = qkv + (size_t)b * S * ld + hq * 64;
+    const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * 64;
+    const bf16_t* Vp = qkv + (size_t)b * S * ld + (H + KV + kvh) * 64;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q_base = qb * 128;
+    const int qw = q_base + 32 * wave;
+    const int qrow = qw + r;
+    const int qc = qrow < S ? qrow : S - 1;
+    const float c2 = scale * 1.4426950408889634f;
+
+    bf16x8 qf[4], dof[4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qp + (size_t)qc * ld + 16 * ks + 8 * h);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(dout + ((size_t)b * S + qc) * ldo + hq * 64 + 16 * ks + 8 * h);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + ((size_t)b * S + qc) * ldo + hq * 64 + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[j]);
+    }
+    const float my_delta = halves_sum(dsum);
+    if (h == 0 && qrow < S) delta[((size_t)b * H + hq) * S + qrow] = my_delta;
+    const float nlse2 = -lse[((size_t)b * H + hq) * S + qc] * 1.4426950408889634f;
+
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    unsigned koff[4];                                    // row fragments of the K image; the V image's are + TILE
+    {
+        const int fx = swz(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) koff[ks] = sbase + r * 128 + (((2 * ks + h) ^ fx) << 4);
+    }
+    unsigned toff[2][2];                                 // transposed fragments of the K image (see the forward's voff)
+    {
+        const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = 8 * u + 4 * (g >> 1) + q4;
+                const int ch = 4 * dt + 2 * (g & 1) + (p >> 1);
+                toff[dt][u] = sbase + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
+            }
+    }
+
+    int lastq = q_base + 127;
+    lastq = lastq < S ? lastq : S - 1;
+    const int nkb = lastq / 64 + 1;
+    int lastw = qw + 31;
+    lastw = lastw < S ? lastw : S - 1;
+    const int ntw = qw < S ? lastw / 32 + 1 : 0;
+
+    unsigned dma_off[2];
+    dma_lane_off(ld, wave, lane, dma_off);
+    auto issue = [&](int kb, int st) {
+        dma_tile(Kp, ld, S, kb * 64, smem + st * STAGE, wave, lane, dma_off);
+        dma_tile(Vp, ld, S, kb * 64, smem + st * STAGE + TILE, wave, lane, dma_off);
+    };
+
+    f32x16 dq0, dq1, zero16, nd16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq0[i] = 0.f; dq1[i] = 0.f; zero16[i] = 0.f; nd16[i] = -my_delta; }
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define DS2(I_) { cs[I_] = fexp2(fmaf(cs[I_], c2, nlse2)) * cdp[I_]; cs[I_ + 1] = fexp2(fmaf(cs[I_ + 1], c2, nlse2)) * cdp[I_ + 1]; }
+    // one 32-key tile; on entry cs / cdp = S^T and dP^T - delta of this tile, kf / vf = K and V row fragments of the next
+    bf16x8 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
+    auto step = [&](auto a_tag, auto ann_tag, int key0, f32x16& cs, f32x16& cdp, f32x16& ns, f32x16& ndp) {
+        constexpr int A = decltype(a_tag)::value, ANN = decltype(ann_tag)::value;
+        // K^T fragments of this tile: [k-step s][row half dt][row group u]
+        const bf16x4 t000 = tr_read<A>(toff[0][0]), t001 = tr_read<A>(toff[0][1]);
+        const bf16x4 t010 = tr_read<A>(toff[1][0]), t011 = tr_read<A>(toff[1][1]);
+        const bf16x4 t100 = tr_read<A + 2048>(toff[0][0]), t101 = tr_read<A + 2048>(toff[0][1]);
+        const bf16x4 t110 = tr_read<A + 2048>(toff[1][0]), t111 = tr_read<A + 2048>(toff[1][1]);
+        if (key0 + 31 > qw) {                           // diagonal tile: exp2(-inf) = 0 kills the masked scores
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (key0 + (i & 3) + 8 * (i >> 2) + 4 * h > qrow) cs[i] = -INFINITY;
+        }
+        LGKM_WAIT(8);                                    // kf / vf (requested one step ago) have landed
+        ns = MFMA32(kf0, qf[0], zero16); SB(); DS2(0) SB();
+        ndp = MFMA32(vf0, dof[0], nd16); SB(); DS2(2) SB();
+        ns = MFMA32(kf1, qf[1], ns); SB(); DS2(4) SB();
+        ndp = MFMA32(vf1, dof[1], ndp); SB(); DS2(6) SB();
+        ns = MFMA32(kf2, qf[2], ns); SB(); DS2(8) SB();
+        ndp = MFMA32(vf2, dof[2], ndp); SB(); DS2(10) SB();
+        ns = MFMA32(kf3, qf[3], ns); SB(); DS2(12) SB();
+        ndp = MFMA32(vf3, dof[3], ndp); SB(); DS2(14) SB();
+        const bf16x8 p0 = pack8f(cs, 0), p1 = pack8f(cs, 1);
+        LGKM_WAIT(0);
+        kf0 = row_read<ANN>(koff[0]); kf1 = row_read<ANN>(koff[1]); kf2 = row_read<ANN>(koff[2]); kf3 = row_read<ANN>(koff[3]);
+        vf0 = row_read<ANN + TILE>(koff[0]); vf1 = row_read<ANN + TILE>(koff[1]); vf2 = row_read<ANN + TILE>(koff[2]); vf3 = row_read<ANN + TILE>(koff[3]);
+        dq0 = MFMA32(cat4(t000, t001), p0, dq0);
+        dq1 = MFMA32(cat4(t010, t011), p0, dq1);
+        dq0 = MFMA32(cat4(t100, t101), p1, dq0);
+        dq1 = MFMA32(cat4(t110, t111), p1, dq1);
+    };
+#undef DS2
+
+    issue(0, 0);
+    if (nkb > 1) { issue(1, 1); VM_WAIT(4); } else { VM_WAIT(0); }
+    __builtin_amdgcn_s_barrier();
+
+    using P00 = std::integral_constant<int, 0>;
+    using P01 = std::integral_constant<int, 4096>;
+    using P10 = std::integral_constant<int, STAGE>;
+    using P11 = std::integral_constant<int, STAGE + 4096>;
+    using P20 = std::integral_constant<int, 2 * STAGE>;
+    using P21 = std::integral_constant<int, 2 * STAGE + 4096>;
+    f32x16 sa, sb, da, db;
+    if (ntw > 0) {
+        bf16x8 k0 = row_read<0>(koff[0]), k1 = row_read<0>(koff[1]), k2 = row_read<0>(koff[2]), k3 = row_read<0>(koff[3]);
+        bf16x8 v0 = row_read<TILE>(koff[0]), v1 = row_read<TILE>(koff[1]), v2 = row_read<TILE>(koff[2]), v3 = row_read<TILE>(koff[3]);
+        kf0 = row_read<4096>(koff[0]); kf1 = row_read<4096>(koff[1]); kf2 = row_read<4096>(koff[2]); kf3 = row_read<4096>(koff[3]);
+        vf0 = row_read<TILE + 4096>(koff[0]); vf1 = row_read<TILE + 4096>(koff[1]); vf2 = row_read<TILE + 4096>(koff[2]); vf3 = row_read<TILE + 4096>(koff[3]);
+        LGKM_WAIT(8);
+        sa = MFMA32(k0, qf[0], zero16); sa = MFMA32(k1, qf[1], sa); sa = MFMA32(k2, qf[2], sa); sa = MFMA32(k3, qf[3], sa);
+        da = MFMA32(v0, dof[0], nd16); da = MFMA32(v1, dof[1], da); da = MFMA32(v2, dof[2], da); da = MFMA32(v3, dof[3], da);
+    }
+#define BLOCK(KB, C0, C1, N0, N1, NNIDX)                                                                               \
+    {                                                                                                                  \
+        VM_WAIT(0);                                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        if ((KB) + 2 < nkb) issue((KB) + 2, NNIDX);                                                                    \
+        if (2 * (KB) < ntw) step(C0{}, N0{}, (KB) * 64, sa, da, sb, db);                                               \
+        if (2 * (KB) + 1 < ntw) step(C1{}, N1{}, (KB) * 64 + 32, sb, db, sa, da);                                      \
+    }
+    for (int kb = 0; kb < nkb; kb += 3) {
+        BLOCK(kb, P00, P01, P10, P11, 2)
+        if (kb + 1 >= nkb) break;
+        BLOCK(kb + 1, P10, P11, P20, P21, 0)
+        if (kb + 2 >= nkb) break;
+        BLOCK(kb + 2, P20, P21, P00, P01, 1)
+    }
+#undef BLOCK
+#undef SB
+
+    // ---- epilogue: dQ^T registers (x 1/sqrt(hd), RoPE^T) -> LDS [q][d] -> whole 128-B rows of the q block of dqkv
+    __builtin_amdgcn_s_barrier();
+    {
+        char* ob = smem + wave * (32 * 144);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float a0 = dq0[4 * gq] * scale, a1 = dq0[4 * gq + 1] * scale, a2 = dq0[4 * gq + 2] * scale, a3 = dq0[4 * gq + 3] * scale;
+            float b0 = dq1[4 * gq] * scale, b1 = dq1[4 * gq + 1] * scale, b2 = dq1[4 * gq + 2] * scale, b3 = dq1[4 * gq + 3] * scale;
+            if (rope) {
+                unrope2(rope, qc, 64, 4 * gq + 2 * h, a0, a1, a2, a3);
+                unrope2(rope, qc, 64, 16 + 4 * gq + 2 * h, b0, b1, b2, b3);
+            }
+            uint2 w0, w1;
+            w0.x = pack2bf(a0, a1); w0.y = pack2bf(a2, a3);
+            w1.x = pack2bf(b0, b1); w1.y = pack2bf(b2, b3);
+            *reinterpret_cast<uint2*>(ob + r * 144 + (8 * gq + 4 * h) * 2) = w0;
+            *reinterpret_cast<uint2*>(ob + r * 144 + (32 + 8 * gq + 4 * h) * 2) = w1;
+        }
+        bf16_t* op = dqkv + ((size_t)b * S) * ld + hq * 64;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = 8 * pass + (lane >> 3);
+            const U4 v = *reinterpret_cast<const U4*>(ob + row * 144 + (lane & 7) * 16);
+            if (qw + row < S) *reinterpret_cast<U4*>(op + (size_t)(qw + row) * ld + (lane & 7) * 8) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dK / dV: workgroup = 64 keys of one (b, kv-head), 4 waves: wave w owns key half (w & 1) - 32 keys on its lanes, their
+// K^T / V^T fragments in registers for the whole kernel - and takes the 32-query tile of parity (w >> 1) of every
+// 64-query block, so two waves share each key half and their dK^T / dV^T accumulators are added through LDS at the end
+// (no atomics, a fixed order: deterministic).  The workgroup walks the 4 q-heads of the group x the query blocks at or
+// below the diagonal; Q and dO blocks arrive by LDS-DMA into a 3-stage ring (ONE image each, read by rows for S and dP and
+// transposed for dK^T and dV^T), lse and delta go through registers so that they land in LDS as -lse*log2(e) and -delta:
+// the first is the addend of the exp2 argument, the second is read straight into the accumulators dP starts from.
+//   S = Q K^T, dP = dO V^T - delta (query on the register index, key on the lane)  ->  P = exp2(c S - lse), dS = P o dP
+//   dV^T += dO^T P, dK^T += Q^T dS   (P / dS leave their accumulators as the B operand, k = query)
+template <int OFF>
+__device__ __forceinline__ f32x4 stat_read(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+constexpr int KSTAGE = 2 * TILE + 512;      // Q image + dO image + 64 x (-lse*log2e) + 64 x (-delta)
+
+__global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale,
+                                                            const float* __restrict__ rope) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rep = H / KV;
+    const int nkblk = (S + 63) / 64;
+    int kblk, kvh, b;
+    {   // XCD-aware 1-D grid: a contiguous run of (b, kv-head) pairs per XCD, the heaviest key blocks of the run first
+        const int T = gridDim.x, id = blockIdx.x, xcd = id & 7, within = id >> 3;
+        const int q8 = T >> 3, r8 = T & 7;
+        const int nid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+        int pair = nid / nkblk;
+        kblk = nid % nkblk;
+        const int run = (xcd < r8) ? q8 + 1 : q8, base = nid - within;
+        if (run % nkblk == 0 && base % nkblk == 0) {
+            const int npairs = run / nkblk;
+            kblk = within / npairs;
+            pair = base / nkblk + within % npairs;
+        }
+        kvh = pair % KV;
+        b = pair / KV;
+    }
+    const int ld = (H + 2 * KV) * 64, ldo = H * 64;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kh = wave & 1, qp = wave >> 1;
+    const int key0w = kblk * 64 + 32 * kh;               // first key of this wave
+    const int key = key0w + r;
+    const int kc = key < S ? key : S - 1;
+    const float c2 = scale * 1.4426950408889634f;
+
+    bf16x8 kf[4], vf[4];                                 // B operands: K^T / V^T [d][key], key on the lane
+    {
+        const bf16_t* Kp = qkv + ((size_t)b * S + kc) * ld + (H + kvh) * 64;
+        const bf16_t* Vp = qkv + ((size_t)b * S + kc) * ld + (H + KV + kvh) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(Kp + 16 * ks + 8 * h);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(Vp + 16 * ks + 8 * h);
+        }
+    }
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    unsigned roff[4];                                    // row fragments of this wave's query tile (Q image; dO image + TILE)
+    {
+        const int fx = swz(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) roff[ks] = sbase + qp * 4096 + r * 128 + (((2 * ks + h) ^ fx) << 4);
+    }
+    unsigned toff[2][2];                                 // transposed fragments of the tile (k = query rows)
+    {
+        const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = 8 * u + 4 * (g >> 1) + q4;
+                const int ch = 4 * dt + 2 * (g & 1) + (p >> 1);
+                toff[dt][u] = sbase + qp * 4096 + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
+            }
+    }
+    const unsigned soff = sbase + 2 * TILE + (32 * qp + 4 * h) * 4;      // stats of queries 32 qp + 4h + {0..3} (+ 8k: immediate 32 k)
+
+    const int nqb = (S + 63) / 64;
+    const int per_head = nqb - kblk;                     // query blocks at or below the diagonal
+    const int niter = rep * per_head;
+
+    unsigned dma_q[2], dma_o[2];
+    dma_lane_off(ld, wave, lane, dma_q);
+    dma_lane_off(ldo, wave, lane, dma_o);
+    float streg = 0.f;                                   // one lse / delta value per thread (threads 0..127), a block ahead
+    auto issue = [&](int it, int st) {
+        const int hh = it / per_head, qb = kblk + it % per_head;
+        const int hq = kvh * rep + hh;
+        dma_tile(qkv + (size_t)b * S * ld + hq * 64, ld, S, qb * 64, smem + st * KSTAGE, wave, lane, dma_q);
+        dma_tile(dout + (size_t)b * S * ldo + hq * 64, ldo, S, qb * 64, smem + st * KSTAGE + TILE, wave, lane, dma_o);
+        if (threadIdx.x < 128) {
+            int q = qb * 64 + (threadIdx.x & 63);
+            q = q < S ? q : S - 1;
+            const size_t idx = ((size_t)b * H + hq) * S + q;
+            streg = threadIdx.x < 64 ? -lse[idx] * 1.4426950408889634f : -delta[idx];
+        }
+    };
+    auto commit_stats = [&](int st) {
+        if (threadIdx.x < 128) *reinterpret_cast<float*>(smem + st * KSTAGE + 2 * TILE + threadIdx.x * 4) = streg;
+    };
+
+    f32x16 dk0, dk1, dv0, dv1, zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; zero16[i] = 0.f; }
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    // Row fragments and statistics of the NEXT tile are requested while the current tile's last four MFMAs run (their
+    // registers are free by then), so a tile never starts by waiting for LDS.  Every wave runs every query block - a tile
+    // entirely above the diagonal (one per wave at most) is masked to zero rather than skipped - so there is one code path.
+    bf16x8 qr0, qr1, qr2, qr3, or0, or1, or2, or3;
+    f32x4 n0, n1, n2, n3, e0, e1, e2, e3;
+    auto fetch = [&](auto a_tag) {
+        constexpr int A = decltype(a_tag)::value;
+        qr0 = row_read<A>(roff[0]); qr1 = row_read<A>(roff[1]); qr2 = row_read<A>(roff[2]); qr3 = row_read<A>(roff[3]);
+        or0 = row_read<A + TILE>(roff[0]); or1 = row_read<A + TILE>(roff[1]); or2 = row_read<A + TILE>(roff[2]); or3 = row_read<A + TILE>(roff[3]);
+        n0 = stat_read<A>(soff); n1 = stat_read<A + 32>(soff); n2 = stat_read<A + 64>(soff); n3 = stat_read<A + 96>(soff);
+        e0 = stat_read<A + 256>(soff); e1 = stat_read<A + 288>(soff); e2 = stat_read<A + 320>(soff); e3 = stat_read<A + 352>(soff);
+    };
+    auto tile = [&](auto a_tag, auto an_tag, int q0) {
+        constexpr int A = decltype(a_tag)::value;
+        // dO^T and Q^T fragments: [k-step s][row half dt][row group u]
+        const bf16x4 u000 = tr_read<A + TILE>(toff[0][0]), u001 = tr_read<A + TILE>(toff[0][1]);
+        const bf16x4 u010 = tr_read<A + TILE>(toff[1][0]), u011 = tr_read<A + TILE>(toff[1][1]);
+        const bf16x4 w000 = tr_read<A>(toff[0][0]), w001 = tr_read<A>(toff[0][1]);
+        const bf16x4 w010 = tr_read<A>(toff[1][0]), w011 = tr_read<A>(toff[1][1]);
+        LGKM_WAIT(8);                                    // rows + stats (requested during the previous tile) have landed
+        f32x16 nl, dp, sc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nl[j] = n0[j]; nl[4 + j] = n1[j]; nl[8 + j] = n2[j]; nl[12 + j] = n3[j];
+                                      dp[j] = e0[j]; dp[4 + j] = e1[j]; dp[8 + j] = e2[j]; dp[12 + j] = e3[j]; }
+        sc = MFMA32(qr0, kf[0], zero16); dp = MFMA32(or0, vf[0], dp);
+        sc = MFMA32(qr1, kf[1], sc); dp = MFMA32(or1, vf[1], dp);
+        sc = MFMA32(qr2, kf[2], sc); dp = MFMA32(or2, vf[2], dp);
+        sc = MFMA32(qr3, kf[3], sc); dp = MFMA32(or3, vf[3], dp);
+        const bf16x4 u100 = tr_read<A + TILE + 2048>(toff[0][0]), u101 = tr_read<A + TILE + 2048>(toff[0][1]);
+        const bf16x4 u110 = tr_read<A + TILE + 2048>(toff[1][0]), u111 = tr_read<A + TILE + 2048>(toff[1][1]);
+        const bf16x4 w100 = tr_read<A + 2048>(toff[0][0]), w101 = tr_read<A + 2048>(toff[0][1]);
+        const bf16x4 w110 = tr_read<A + 2048>(toff[1][0]), w111 = tr_read<A + 2048>(toff[1][1]);
+        const bool edge = (q0 < key0w + 32) || (q0 + 32 > S);   // the tile touches the diagonal or the sequence end (wave-uniform)
+#define PD(I_)                                                                                                          \
+        {                                                                                                              \
+            float p_ = fexp2(fmaf(sc[I_], c2, nl[I_]));                                                                \
+            if (edge) { const int q_ = q0 + ((I_) & 3) + 8 * ((I_) >> 2) + 4 * h; if (key > q_ || q_ >= S) p_ = 0.f; }  \
+            sc[I_] = p_; dp[I_] = p_ * dp[I_];                                                                         \
+        }
+        PD(0) PD(1) PD(2) PD(3) PD(4) PD(5) PD(6) PD(7)
+        const bf16x8 p0 = pack8f(sc, 0), d0 = pack8f(dp, 0);
+        LGKM_WAIT(8);                                    // first k-step's transposed fragments
+        dv0 = MFMA32(cat4(u000, u001), p0, dv0); SB(); PD(8) PD(9) SB();
+        dk0 = MFMA32(cat4(w000, w001), d0, dk0); SB(); PD(10) PD(11) SB();
+        dv1 = MFMA32(cat4(u010, u011), p0, dv1); SB(); PD(12) PD(13) SB();
+        dk1 = MFMA32(cat4(w010, w011), d0, dk1); SB(); PD(14) PD(15) SB();
+#undef PD
+        const bf16x8 p1 = pack8f(sc, 1), d1 = pack8f(dp, 1);
+        LGKM_WAIT(0);
+        fetch(an_tag);                                   // next tile's rows + stats fly under the last four MFMAs
+        dv0 = MFMA32(cat4(u100, u101), p1, dv0);
+        dk0 = MFMA32(cat4(w100, w101), d1, dk0);
+        dv1 = MFMA32(cat4(u110, u111), p1, dv1);
+        dk1 = MFMA32(cat4(w110, w111), d1, dk1);
+    };
+#undef SB
+
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, KSTAGE>;
+    using K2 = std::integral_constant<int, 2 * KSTAGE>;
+    if (niter > 0) {
+        issue(0, 0);
+        VM_WAIT(0);
+        commit_stats(0);
+        __builtin_amdgcn_s_barrier();
+        fetch(K0{});                                     // the first tile's rows + stats (later ones ride under the previous tile)
+        if (niter > 1) issue(1, 1);
+    }
+    // one query block per step: after the wait, the Q / dO images of blocks it and it+1 (DMA issued two / one step ago) and
+    // the stats of block it+1 (in registers) are complete; the stats are committed, the barrier publishes everything and
+    // releases the stage of block it-1, whose successor (block it+2) is then requested.  A tile reads block it and, at
+    // its end, prefetches from block it+1.
+#define KBLOCK(IT, SC_, SN_, NIDX, NNIDX)                                                                              \
+    {                                                                                                                  \
+        VM_WAIT(0);                                                                                                    \
+        if ((IT) + 1 < niter) commit_stats(NIDX);                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        if ((IT) + 2 < niter) issue((IT) + 2, NNIDX);                                                                  \
+        tile(SC_{}, SN_{}, (kblk + (IT) % per_head) * 64 + 32 * qp);                                                   \
+    }
+    for (int it = 0; it < niter; it += 3) {
+        KBLOCK(it, K0, K1, 1, 2)
+        if (it + 1 >= niter) break;
+        KBLOCK(it + 1, K1, K2, 2, 0)
+        if (it + 2 >= niter) break;
+        KBLOCK(it + 2, K2, K0, 0, 1)
+    }
+#undef KBLOCK
+
+    // ---- reduce the two query-parity waves of each key half through LDS, then dK^T / dV^T -> [key][d] rows
+    __builtin_amdgcn_s_barrier();
+    {
+        float* red = reinterpret_cast<float*>(smem) + kh * (64 * 64);    // [reg 0..63][lane] per key half
+        if (qp == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                red[(i) * 64 + lane] = dk0[i]; red[(16 + i) * 64 + lane] = dk1[i];
+                red[(32 + i) * 64 + lane] = dv0[i]; red[(48 + i) * 64 + lane] = dv1[i];
+            }
+        }
+        __syncthreads();
+        if (qp == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                dk0[i] += red[(i) * 64 + lane]; dk1[i] += red[(16 + i) * 64 + lane];
+                dv0[i] += red[(32 + i) * 64 + lane]; dv1[i] += red[(48 + i) * 64 + lane];
+            }
+        }
+        __syncthreads();
+        if (qp == 0) {
+            char* ob = smem + kh * (2 * 32 * 144);      // [K rows | V rows] of this key half, 144-B rows
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float a0 = dk0[4 * gq] * scale, a1 = dk0[4 * gq + 1] * scale, a2 = dk0[4 * gq + 2] * scale, a3 = dk0[4 * gq + 3] * scale;
+                float b0 = dk1[4 * gq] * scale, b1 = dk1[4 * gq + 1] * scale, b2 = dk1[4 * gq + 2] * scale, b3 = dk1[4 * gq + 3] * scale;
+                if (rope) {
+                    unrope2(rope, kc, 64, 4 * gq + 2 * h, a0, a1, a2, a3);
+                    unrope2(rope, kc, 64, 16 + 4 * gq + 2 * h, b0, b1, b2, b3);
+                }
+                uint2 w0, w1, x0, x1;
+                w0.x = pack2bf(a0, a1); w0.y = pack2bf(a2, a3);
+                w1.x = pack2bf(b0, b1); w1.y = pack2bf(b2, b3);
+                x0.x = pack2bf(dv0[4 * gq], dv0[4 * gq + 1]); x0.y = pack2bf(dv0[4 * gq + 2], dv0[4 * gq + 3]);
+                x1.x = pack2bf(dv1[4 * gq], dv1[4 * gq + 1]); x1.y = pack2bf(dv1[4 * gq + 2], dv1[4 * gq + 3]);
+                *reinterpret_cast<uint2*>(ob + r * 144 + (8 * gq + 4 * h) * 2) = w0;
+                *reinterpret_cast<uint2*>(ob + r * 144 + (32 + 8 * gq + 4 * h) * 2) = w1;
+                *reinterpret_cast<uint2*>(ob + 32 * 144 + r * 144 + (8 * gq + 4 * h) * 2) = x0;
+                *reinterpret_cast<uint2*>(ob + 32 * 144 + r * 144 + (32 + 8 * gq + 4 * h) * 2) = x1;
+            }
+            bf16_t* kp = dqkv + ((size_t)b * S) * ld + (H + kvh) * 64;
+            bf16_t* vp = dqkv + ((size_t)b * S) * ld + (H + KV + kvh) * 64;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = 8 * pass + (lane >> 3);
+                const U4 kv_ = *reinterpret_cast<const U4*>(ob + row * 144 + (lane & 7) * 16);
+                const U4 vv_ = *reinterpret_cast<const U4*>(ob + 32 * 144 + row * 144 + (lane & 7) * 16);
+                if (key0w + row < S) {
+                    *reinterpret_cast<U4*>(kp + (size_t)(key0w + row) * ld + (lane & 7) * 8) = kv_;
+                    *reinterpret_cast<U4*>(vp + (size_t)(key0w + row) * ld + (lane & 7) * 8) = vv_;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int csm_attn64_fwd_launch(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, hipStream_t stream) {
@@ -351,5 +798,25 @@ int csm_attn64_fwd_launch(const void* qkv, void* out, float* lse, int B, int S, 
     const int lds = NSTAGE * STAGE;
     dim3 grid((unsigned)(((S + 127) / 128) * H * B)), block(256);
     hipLaunchKernelGGL(attn64_fwd_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, S, H, KV, scale);
+    return 0;
+}
+
+int csm_attn64_dq_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int S,
+                         int H, int KV, const float* rope, hipStream_t stream) {
+    const float scale = 0.125f;
+    const int lds = NSTAGE * STAGE;
+    dim3 grid((unsigned)(((S + 127) / 128) * H * B)), block(256);
+    hipLaunchKernelGGL(attn64_dq_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta,
+                       (bf16_t*)dqkv, S, H, KV, scale, rope);
+    return 0;
+}
+
+int csm_attn64_dkv_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
+                          int KV, const float* rope, hipStream_t stream) {
+    const float scale = 0.125f;
+    const int lds = NSTAGE * KSTAGE;
+    dim3 grid((unsigned)(((S + 63) / 64) * KV * B)), block(256);
+    hipLaunchKernelGGL(attn64_dkv_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv,
+                       S, H, KV, scale, rope);
     return 0;
 }
