@@ -678,13 +678,14 @@ __global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __rest
         const bf16x4 u110 = tr_read<A + TILE + 2048>(toff[1][0]), u111 = tr_read<A + TILE + 2048>(toff[1][1]);
         const bf16x4 w100 = tr_read<A + 2048>(toff[0][0]), w101 = tr_read<A + 2048>(toff[0][1]);
         const bf16x4 w110 = tr_read<A + 2048>(toff[1][0]), w111 = tr_read<A + 2048>(toff[1][1]);
-        const bool edge = (q0 < key0w + 32) || (q0 + 32 > S);   // the tile touches the diagonal or the sequence end (wave-uniform)
-#define PD(I_)                                                                                                          \
-        {                                                                                                              \
-            float p_ = fexp2(fmaf(sc[I_], c2, nl[I_]));                                                                \
-            if (edge) { const int q_ = q0 + ((I_) & 3) + 8 * ((I_) >> 2) + 4 * h; if (key > q_ || q_ >= S) p_ = 0.f; }  \
-            sc[I_] = p_; dp[I_] = p_ * dp[I_];                                                                         \
+        if ((q0 < key0w + 32) || (q0 + 32 > S)) {       // the tile touches the diagonal or the sequence end (wave-uniform):
+#pragma unroll                                          // exp2(-inf) = 0 kills the masked scores, no branch inside the element loop
+            for (int i = 0; i < 16; ++i) {
+                const int q_ = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key > q_ || q_ >= S) sc[i] = -INFINITY;
+            }
         }
+#define PD(I_) { const float p_ = fexp2(fmaf(sc[I_], c2, nl[I_])); sc[I_] = p_; dp[I_] = p_ * dp[I_]; }
         PD(0) PD(1) PD(2) PD(3) PD(4) PD(5) PD(6) PD(7)
         const bf16x8 p0 = pack8f(sc, 0), d0 = pack8f(dp, 0);
         LGKM_WAIT(8);                                    // first k-step's transposed fragments
