@@ -90,6 +90,17 @@ class GemmTimer:
             timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1, batch * (2.0 * (M * K + N * K) + esz * M * N)))
             return out
 
+        self.orig_rope = ops.linear_rope_fwd
+
+        def fused_rope(x, w, out, table, S, n_rope_cols, head_dim):      # q|k|v projection with RoPE in the epilogue
+            e0, e1 = ev()
+            e0.record(); r = timer.orig_rope(x, w, out, table, S, n_rope_cols, head_dim); e1.record()
+            M, K = x.shape
+            N = w.shape[0]
+            timer.records.append(("nt_fwd_bf16", 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
+            return r
+
+        ops.linear_rope_fwd = fused_rope
         self.orig_adamw = ops.adamw_step
         self.hbm = []
 
@@ -105,6 +116,7 @@ class GemmTimer:
     def __exit__(self, *a):
         self.ops.gemm, self.ops.linear_swiglu_fwd, self.ops.linear_dx_swiglu_bwd = self.orig, self.orig_fwd, self.orig_bwd
         self.ops.adamw_step = self.orig_adamw
+        self.ops.linear_rope_fwd = self.orig_rope
 
     def adamw_summary(self):
         torch.cuda.synchronize()

@@ -26,6 +26,7 @@ F32 = torch.float32
 import os as _os
 FUSE_SWIGLU = _os.environ.get("CSM_FUSE_SWIGLU", "1") == "1"
 FUSE_ROPE_BWD = _os.environ.get("CSM_FUSE_ROPE_BWD", "1") == "1"      # A/B switch: RoPE backward inside the attention backward
+FUSE_ROPE_FWD = _os.environ.get("CSM_FUSE_ROPE_FWD", "1") == "1"      # A/B switch: RoPE forward inside the q|k|v GEMM epilogue
 
 
 class _Stack:
@@ -44,7 +45,8 @@ class _Stack:
         return lo.get(self.prefix, layer, module) if lo is not None else None
 
     # -------------------------------------------------------------------------------------------- forward
-    def forward(self, x: torch.Tensor, B: int, S: int, save: bool, pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, B: int, S: int, save: bool, pos: Optional[torch.Tensor] = None,
+                fuse_rope: bool = True) -> torch.Tensor:
         c, dev = self.c, x.device
         M, d = x.shape
         H, KV, hd, F = c.num_heads, c.num_kv_heads, c.head_dim, c.intermediate_dim
@@ -56,13 +58,17 @@ class _Stack:
             rstd1 = torch.empty(M, dtype=F32, device=dev)
             ops.rmsnorm_fwd(x, self.w(f"layers.{i}.sa_norm.scale"), xn, rstd1, c.norm_eps)
             qkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
-            ops.linear_fwd(xn, self.w(f"layers.{i}.attn.qkv"), qkv)
             hq, hk = H * hd, KV * hd
-            for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
-                ad = self._lora(i, mod)
-                if ad is not None:
-                    a[f"t_{mod}"] = ad.forward(xn, qkv[:, lo_:hi_])
-            ops.rope(qkv, table, S, H + KV, hd, pos=pos)
+            if FUSE_ROPE_FWD and fuse_rope and pos is None and not any(self._lora(i, mod) is not None for mod in ("q_proj", "k_proj", "v_proj")):
+                # positions = arange(S) and nothing to add before the rotation: RoPE rides in the projection's epilogue
+                ops.linear_rope_fwd(xn, self.w(f"layers.{i}.attn.qkv"), qkv, table, S, hq + hk, hd)
+            else:
+                ops.linear_fwd(xn, self.w(f"layers.{i}.attn.qkv"), qkv)
+                for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
+                    ad = self._lora(i, mod)
+                    if ad is not None:
+                        a[f"t_{mod}"] = ad.forward(xn, qkv[:, lo_:hi_])
+                ops.rope(qkv, table, S, H + KV, hd, pos=pos)
             o = torch.empty(M, H * hd, dtype=BF16, device=dev)
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
             ops.attn_fwd(qkv, o, lse, B, S, H, KV, hd)
@@ -582,7 +588,9 @@ class Engine:
             L = cur.shape[1]
             x0 = torch.empty(Bn * L, dd, dtype=BF16, device=dev)
             ops.linear_fwd(cur.reshape(Bn * L, d).contiguous(), m.block("projection.weight"), x0)
-            xf = self.decoder.forward(x0, Bn, L, False).view(Bn, L, dd)
+            # (fuse_rope=False: round q/k to bf16 before the rotation, exactly as the decode kernels of the KV-cache path do, so
+            #  that the two paths stay comparable bit for bit on the frame they both compute from scratch)
+            xf = self.decoder.forward(x0, Bn, L, False, fuse_rope=False).view(Bn, L, dd)
             lg = torch.empty(Bn, Vp, dtype=F32, device=dev)
             ops.gemm(xf[:, -1, :].contiguous(), ah[i - 1], lg, None, False, True)
             ci = draw(lg, i)

@@ -65,6 +65,17 @@ def linear_dx_swiglu_bwd(dy, w2, gu, dgu):
                                gu.data_ptr(), None, 2 * F, _stream()), "csm_gemm_bf16_ex(swiglu bwd)")
 
 
+def linear_rope_fwd(x, w, out, table, S, n_rope_cols, head_dim):
+    """out[M,N] = x[M,K] w[N,K]^T with RoPE (positions = row % S) applied to columns [0, n_rope_cols) in the GEMM epilogue."""
+    pa, M, K, lda = _mat(x)
+    pb, N, Kb, ldb = _mat(w)
+    assert K == Kb and out.shape == (M, N) and out.dtype == BF16 and out.stride(1) == 1
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[0] >= S and table.shape[1] * 2 == head_dim
+    check(lib.csm_gemm_bf16_rope(pa, pb, out.data_ptr(), M, N, K, lda, ldb, out.stride(0), table.data_ptr(), S, n_rope_cols, head_dim,
+                                 _stream()), "csm_gemm_bf16_rope")
+    return out
+
+
 def linear_fwd(x, w, out, residual=None, alpha=1.0):
     """out[M,N] = x[M,K] w[N,K]^T (+ residual)."""
     return gemm(x, w, out, residual, False, False, alpha)

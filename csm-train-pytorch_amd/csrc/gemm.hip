@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
     e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
     e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
-    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
+    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N; e.p0 = g.epi_p0; e.p1 = g.epi_p1;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -150,7 +150,7 @@ int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                        int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
                        long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
-                       hipStream_t stream);
+                       hipStream_t stream, int epi_p0 = 0, int epi_p1 = 0);
 
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
@@ -173,10 +173,10 @@ extern "C" int csm_set_gemm_variant(int v) {
 
 // epilogue: 0 none; 1 SwiGLU forward (C = gate/up interleaved [M][N], aux_out = act [M][N/2]); 2 SwiGLU backward
 // (GEMM computes d(act) [M][N]; aux_in = gate/up [M][2N]; C = d(gate/up) interleaved [M][2N], ldc >= 2N)
-extern "C" int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
-                                int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
-                                long long strideA, long long strideB, long long strideC, long long strideR, int epilogue,
-                                const void* aux_in, void* aux_out, int ld_aux, hipStream_t stream) {
+static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                         int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
+                         long long strideA, long long strideB, long long strideC, long long strideR, int epilogue,
+                         const void* aux_in, void* aux_out, int ld_aux, hipStream_t stream, int epi_p0, int epi_p1) {
     CSM_REQUIRE(A && B && C, "csm_gemm_bf16: null operand");
     CSM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "csm_gemm_bf16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     CSM_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "csm_gemm_bf16: lda/ldb must be multiples of 8 (lda=%d ldb=%d)", lda, ldb);
@@ -191,11 +191,12 @@ extern "C" int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     //  which a LoRA adapter's (alpha/r) t B^T, written first, joins the frozen w1/w3 product without leaving the fused path)
     if (epilogue == 1) CSM_REQUIRE(!out_f32 && aux_out && (N & 3) == 0 && (ldc & 3) == 0 && ld_aux >= N / 2 && (ld_aux & 1) == 0, "csm_gemm_bf16_ex: bad SwiGLU-forward epilogue arguments");
     if (epilogue == 2) CSM_REQUIRE(!out_f32 && aux_in && (N & 3) == 0 && (ldc & 7) == 0 && (ld_aux & 7) == 0 && ld_aux >= 2 * N && !R && ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)C & 15) == 0, "csm_gemm_bf16_ex: bad SwiGLU-backward epilogue arguments");
-    CSM_REQUIRE(epilogue >= 0 && epilogue <= 2, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
+    CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 3 && K % 64 == 0 && M >= 8 && N >= 8))
         return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
-                                  strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream);
+                                  strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1);
     GemmArgs g;
+    g.epi_p0 = epi_p0; g.epi_p1 = epi_p1;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sR = strideR;
@@ -206,6 +207,28 @@ extern "C" int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const voi
     if (!transA && transB) return launch<0, 1>(g, out_f32, batch, stream);
     if (transA && transB) return launch<1, 1>(g, out_f32, batch, stream);
     return launch<1, 0>(g, out_f32, batch, stream);
+}
+
+extern "C" int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                                int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
+                                long long strideA, long long strideB, long long strideC, long long strideR, int epilogue,
+                                const void* aux_in, void* aux_out, int ld_aux, hipStream_t stream) {
+    CSM_REQUIRE(epilogue >= 0 && epilogue <= 2, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
+    return gemm_dispatch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA, strideB, strideC,
+                         strideR, epilogue, aux_in, aux_out, ld_aux, stream, 0, 0);
+}
+
+// Fused q|k|v projection + RoPE (torchtune Llama3ScaledRoPE, reference model.py:23-24,40-41): C[M][N] = A[M][K] W[N][K]^T with the
+// interleaved pairs of columns [0, n_rope_cols) - the q and k heads, head_dim features each - rotated by position
+// (row % rows_per_seq) using the fp32 (cos, sin) table [P][head_dim/2][2].  Positions are the row index inside a sequence
+// (training / prefill); callers with explicit positions use csm_rope after a plain csm_gemm_bf16.
+extern "C" int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                  const float* rope_table, int rows_per_seq, int n_rope_cols, int head_dim, hipStream_t stream) {
+    CSM_REQUIRE(rope_table && rows_per_seq > 0 && head_dim >= 8 && (head_dim & 7) == 0 && n_rope_cols >= 0 && n_rope_cols <= N &&
+                n_rope_cols % head_dim == 0 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0,
+                "csm_gemm_bf16_rope: bad arguments");
+    return gemm_dispatch(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, 0, 0, 0, 1.f, 1, 0, 0, 0, 0, EPI_ROPE, rope_table, nullptr,
+                         rows_per_seq, stream, n_rope_cols, head_dim);
 }
 
 extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,

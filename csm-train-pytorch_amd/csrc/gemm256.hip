@@ -23,6 +23,7 @@ struct Gemm256Args {
     float alpha;
     int tiles_m, tiles_n;
     int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
+    int epi_p0, epi_p1;
 };
 
 // one 16-KiB half-tile by LDS-DMA: 16 pieces of 1 KiB over 8 waves
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
     e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
     e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
-    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N;
+    e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N; e.p0 = g.epi_p0; e.p1 = g.epi_p1;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
     if constexpr (sizeof(OutT) == 2) {
         if (e.mode == EPI_SWIGLU_BWD) {
@@ -232,8 +233,9 @@ int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) 
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                        int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
                        long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
-                       hipStream_t stream) {
+                       hipStream_t stream, int epi_p0, int epi_p1) {
     Gemm256Args g;
+    g.epi_p0 = epi_p0; g.epi_p1 = epi_p1;
     g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;

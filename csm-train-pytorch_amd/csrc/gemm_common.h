@@ -18,6 +18,7 @@ struct GemmArgs {
     float alpha;
     int tiles_m, tiles_n;
     int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
+    int epi_p0, epi_p1;   // EPI_ROPE: columns [0, p0) are rotated, head_dim p1
 };
 
 // ---- staging: each thread moves 4 x 16 B per operand per K-tile --------------------------------
@@ -175,8 +176,28 @@ struct Epi {
     void* C; const bf16_t* R; int ldc, ldr; float alpha;
     int mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
     int M, N;
+    int p0, p1;
 };
-enum { EPI_NONE = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2 };
+// mode 3 (RoPE forward, the fused q|k|v projection): columns n < p0 are (q, k) heads of p1 features whose interleaved pairs
+// (2i, 2i+1) are rotated by row position m % ld_aux with the fp32 (cos, sin) table aux_in = [P][p1/2][2] - torchtune's
+// Llama3ScaledRoPE applied to the fp32 accumulator, one bf16 rounding instead of the stand-alone kernel's two.
+enum { EPI_NONE = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2, EPI_ROPE = 3 };
+
+// rotate NP adjacent pairs v[0..2NP) that start at column n of row m (n even, all pairs inside one head)
+template <int NP>
+__device__ __forceinline__ void epi_rope(const Epi& e, int m, int n, float* v) {
+    if (n >= e.p0) return;
+    const float* table = reinterpret_cast<const float*>(e.aux_in);
+    const int pos = m % e.ld_aux, hd = e.p1;
+    const float* t = table + ((size_t)pos * (hd >> 1) + ((n % hd) >> 1)) * 2;
+#pragma unroll
+    for (int i = 0; i < NP; i += 2) {
+        const float4 cs = *reinterpret_cast<const float4*>(t + 2 * i);      // c_i, s_i, c_{i+1}, s_{i+1}
+        const float a0 = v[2 * i] * cs.x - v[2 * i + 1] * cs.y, a1 = v[2 * i + 1] * cs.x + v[2 * i] * cs.y;
+        const float a2 = v[2 * i + 2] * cs.z - v[2 * i + 3] * cs.w, a3 = v[2 * i + 3] * cs.z + v[2 * i + 2] * cs.w;
+        v[2 * i] = a0; v[2 * i + 1] = a1; v[2 * i + 2] = a2; v[2 * i + 3] = a3;
+    }
+}
 
 template <typename OutT>
 __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int n, const f32x4& a) {
@@ -202,6 +223,7 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
             v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
             v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
         }
+        if (e.mode == EPI_ROPE) epi_rope<2>(e, m, n, v);
         if constexpr (sizeof(OutT) == 2) {
             uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
             *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;
@@ -272,7 +294,7 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
     const int g = lane >> 4;
     bool wide = false;
     if constexpr (sizeof(OutT) == 2)
-        wide = vec_ok && (e.mode == EPI_NONE || (e.mode == EPI_SWIGLU_FWD && (e.ld_aux & 3) == 0)) && (e.ldc & 7) == 0 &&
+        wide = vec_ok && (e.mode == EPI_NONE || e.mode == EPI_ROPE || (e.mode == EPI_SWIGLU_FWD && (e.ld_aux & 3) == 0)) && (e.ldc & 7) == 0 &&
                (!e.R || (e.ldr & 7) == 0) && nb + 31 < e.N && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) &&
                (!e.R || (reinterpret_cast<uintptr_t>(e.R) & 15) == 0);
     if (!wide) {
@@ -296,6 +318,7 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += rr[k];
     }
+    if (e.mode == EPI_ROPE) epi_rope<4>(e, m, n, v);
     *reinterpret_cast<U4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = pack8(v);
     if (e.mode == EPI_SWIGLU_FWD) {   // v = g0,u0,g1,u1,g2,u2,g3,u3 (gate / up interleaved along N): four activations, one 8-byte store
         float a[4];

@@ -49,6 +49,14 @@ int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M
                      int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long strideA,
                      long long strideB, long long strideC, long long strideR, int epilogue, const void* aux_in,
                      void* aux_out, int ld_aux, csm_stream_t stream);
+/* Fused q|k|v projection + RoPE forward: C[M][N] = A[M][K] W[N][K]^T, interleaved pairs of columns [0, n_rope_cols) (the q and
+ * k heads, head_dim features each) rotated by position (row % rows_per_seq) with the fp32 (cos, sin) table
+ * [P][head_dim/2][2].  Replaces torchtune q_proj / k_proj / v_proj + Llama3ScaledRoPE as configured at reference
+ * src/csm/models/model.py:13-25,30-42 (rope_base 500000, scale_factor 32) for positions arange(S)
+ * (src/csm/training/utils.py:81-82). */
+int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                       const float* rope_table, int rows_per_seq, int n_rope_cols, int head_dim, csm_stream_t stream);
+
 
 /* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = the 256x256 pipelined kernel
  * where its tiles fill the chip, else 128x128 (default); 3 force the 256x256 kernel */

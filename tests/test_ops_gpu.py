@@ -192,6 +192,30 @@ def test_rmsnorm(dev, M, D):
     close("rmsnorm dscale", dw, wr.grad, 1e-2)
 
 
+@pytest.mark.parametrize("M,S,H,KV,hd,K", [(100, 50, 4, 2, 64, 256), (96, 32, 2, 1, 128, 192), (4096, 2048, 32, 8, 64, 2048)])
+def test_linear_rope_fused_epilogue(dev, M, S, H, KV, hd, K):
+    """csm_gemm_bf16_rope: the q|k|v projection with RoPE applied to the fp32 accumulators of the q and k columns, against
+    the oracle's projection + torchtune-style rotation (v columns untouched); exercises both GEMM tile kernels and the
+    narrow (column overhang) epilogue path through the ragged first case."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(M + hd)
+    N = (H + 2 * KV) * hd
+    x = rnd((M, K), g, 1.0 if K < 1024 else 0.25)
+    w = rnd((N, K), g, 0.1)
+    table = O.rope_table(max(S, 64), hd)
+    y = x.float() @ w.float().t()
+    pos = (torch.arange(M) % S).view(1, M)
+    ref = y.clone()
+    ref[:, :H * hd] = O.rope(y[:, :H * hd].reshape(1, M, H, hd), table, pos).reshape(M, -1)
+    ref[:, H * hd:(H + KV) * hd] = O.rope(y[:, H * hd:(H + KV) * hd].reshape(1, M, KV, hd), table, pos).reshape(M, -1)
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.linear_rope_fwd(x.to(dev), w.to(dev), out, table.to(dev), S, (H + KV) * hd, hd)
+    close("fused qkv + rope", out, ref, 1.5e-2)
+    plain = torch.empty(M, N, dtype=BF, device=dev)
+    ops.linear_fwd(x.to(dev), w.to(dev), plain)
+    assert torch.equal(out[:, (H + KV) * hd:], plain[:, (H + KV) * hd:]), "v columns must be the plain projection"
+
+
 @pytest.mark.parametrize("hd,H,KV", [(64, 4, 2), (128, 2, 1)])
 def test_rope(dev, hd, H, KV):
     from csm.hip import ops
