@@ -27,6 +27,11 @@ import os as _os
 FUSE_SWIGLU = _os.environ.get("CSM_FUSE_SWIGLU", "1") == "1"
 FUSE_ROPE_BWD = _os.environ.get("CSM_FUSE_ROPE_BWD", "1") == "1"      # A/B switch: RoPE backward inside the attention backward
 FUSE_ROPE_FWD = _os.environ.get("CSM_FUSE_ROPE_FWD", "1") == "1"      # A/B switch: RoPE forward inside the q|k|v GEMM epilogue
+# A/B switch: dgrad + wgrad of a Linear layer as one launch with interleaved tiles (bit mask: 1 w2, 2 w13, 4 output_proj, 8 qkv).
+# OFF by default: measured on the B=4, S=2048 step (tools/probes/pair_ab.sh) every pairing is SLOWER than the two separate
+# launches (73.7 ms/step -> 75.7 with w2 alone, 77.4 w13, 77.1 output_proj, 78.3 qkv, 83.2 all four): de-phasing the CUs'
+# epilogues does not pay for two operand sets competing for each XCD's 4 MiB L2.  Kept as a tested entry point.
+PAIR_DX_DW = int(_os.environ.get("CSM_PAIR_DX_DW", "0"))
 
 
 class _Stack:
@@ -153,7 +158,14 @@ class _Stack:
             # ---- MLP: out = h + w2(act)
             dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
             ad = self._lora(i, "w2")
-            if FUSE_SWIGLU and ad is None:
+            w2_done = False
+            if FUSE_SWIGLU and ad is None and train_base and (PAIR_DX_DW & 1):
+                # dgrad (with the SwiGLU backward in its epilogue) and wgrad of w2 share dx and nothing else: one launch
+                w2_done = ops.linear_dx_dw(dx, self.w(f"layers.{i}.mlp.w2.weight"), dgu, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True),
+                                           accumulate=acc, alpha=alpha, swiglu_gu=a["gu"])
+            if w2_done:
+                pass
+            elif FUSE_SWIGLU and ad is None:
                 ops.linear_dx_swiglu_bwd(dx, self.w(f"layers.{i}.mlp.w2.weight"), a["gu"], dgu)   # d(act) never stored
             else:
                 dact = torch.empty(M, F, dtype=BF16, device=dev)
@@ -162,26 +174,31 @@ class _Stack:
                     ad.backward(a["act"], dx, a["t_w2"], dact)
                 ops.swiglu_bwd(a["gu"], dact, dgu)
                 del dact
-            if train_base:
+            if train_base and not w2_done:
                 ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=acc, alpha=alpha)
             dhn = torch.empty(M, d, dtype=BF16, device=dev)
-            ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
+            if not (train_base and (PAIR_DX_DW & 2) and ops.linear_dx_dw(dgu, self.w(f"layers.{i}.mlp.w13"), dhn, a["hn"],
+                                                                        self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)):
+                ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
+                if train_base:
+                    ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)
             for mod, col in (("w1", 0), ("w3", 1)):
                 ad = self._lora(i, mod)
                 if ad is not None:
                     ad.backward(a["hn"], dgu.view(M, F, 2)[:, :, col].contiguous(), a[f"t_{mod}"], dhn)
-            if train_base:
-                ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)
             del dgu
             dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx)   # + residual path
             # ---- attention: h = x + output_proj(o)
             do = torch.empty(M, H * hd, dtype=BF16, device=dev)
-            ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
+            if not (train_base and (PAIR_DX_DW & 4) and ops.linear_dx_dw(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do, a["o"],
+                                                                        self.w(f"layers.{i}.attn.output_proj.weight", True),
+                                                                        accumulate=acc, alpha=alpha)):
+                ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
+                if train_base:
+                    ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
             ad = self._lora(i, "output_proj")
             if ad is not None:
                 ad.backward(a["o"], dh, a["t_output_proj"], do)
-            if train_base:
-                ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
             dqkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
             if pos is None and FUSE_ROPE_BWD:     # positions = arange(S): the RoPE backward rides in the dQ / dK epilogues
                 ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd, rope_table=table)
@@ -189,13 +206,15 @@ class _Stack:
                 ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd)
                 ops.rope(dqkv, table, S, H + KV, hd, pos=pos, inverse=True)
             dxn = torch.empty(M, d, dtype=BF16, device=dev)
-            ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
+            if not (train_base and (PAIR_DX_DW & 8) and ops.linear_dx_dw(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn, a["xn"],
+                                                                        self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)):
+                ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
+                if train_base:
+                    ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)
             for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
                 ad = self._lora(i, mod)
                 if ad is not None:
                     ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
-            if train_base:
-                ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)
             dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh)
             self.acts[i] = None
             if on_layer_done is not None:

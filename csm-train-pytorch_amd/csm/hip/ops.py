@@ -86,6 +86,23 @@ def linear_dx(dy, w, out, residual=None, alpha=1.0):
     return gemm(dy, w, out, residual, False, True, alpha)
 
 
+def linear_dx_dw(dy, w, dx, x, dw, accumulate=False, alpha=1.0, swiglu_gu=None):
+    """dx[M,Kin] = dy[M,Nout] w[Nout,Kin] and dw[Nout,Kin] (+)= alpha * dy^T x[M,Kin] in ONE launch (tiles of the two
+    products interleaved).  With ``swiglu_gu`` [M, 2 Kin] the first product carries the SwiGLU-backward epilogue and dx is
+    d(gate/up) [M, 2 Kin] (w = w2).  Returns False when the shapes do not suit the paired kernel (caller falls back)."""
+    M, Nout = dy.shape
+    Kin = w.shape[1]
+    if M % 64 or Nout % 64 or Kin % 8 or not (dy.stride(1) == w.stride(1) == x.stride(1) == dw.stride(1) == dx.stride(1) == 1):
+        return False
+    assert w.shape == (Nout, Kin) and x.shape == (M, Kin) and dw.shape == (Nout, Kin), (dy.shape, w.shape, x.shape, dw.shape)
+    assert dx.shape == (M, 2 * Kin if swiglu_gu is not None else Kin)
+    epi, aux, ld_aux = (0, None, 0) if swiglu_gu is None else (2, swiglu_gu.data_ptr(), swiglu_gu.stride(0))
+    check(lib.csm_gemm_bf16_dgrad_wgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), x.data_ptr(), dw.data_ptr(), M, Nout, Kin,
+                                        dy.stride(0), w.stride(0), dx.stride(0), x.stride(0), dw.stride(0), epi, aux, ld_aux,
+                                        int(accumulate), float(alpha), _stream()), "csm_gemm_bf16_dgrad_wgrad")
+    return True
+
+
 _splitk_ws = {}
 
 

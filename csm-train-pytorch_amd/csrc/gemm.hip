@@ -238,3 +238,33 @@ extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* 
     return csm_gemm_bf16_ex(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA, strideB,
                             strideC, strideR, 0, nullptr, nullptr, 0, stream);
 }
+
+int csm_gemm256_pair_launch(const void* dY, const void* W, void* dX, int M, int Nout, int Kin, int ld_dy, int ldw, int ld_dx,
+                            int dx_epi, const void* aux_in, int ld_aux,
+                            const void* X, int ldx, void* dW, int ld_dw, int accumulate, float alpha_w, hipStream_t stream);
+
+// The two backward products of a Linear layer y = x W^T in ONE launch (torchtune nn.Linear backward; reference loop
+// src/csm/training/trainer.py:261-263 `loss.backward()`):
+//   dX[M][Kin]    = dY[M][Nout] . W[Nout][Kin]            (epilogue 0)
+//                 or, epilogue 2, the SwiGLU backward of it: W = w2 [d][F], aux_in = gate/up [M][2F], dX = d(gate/up) [M][2F]
+//   dW[Nout][Kin] (+)= alpha_w * dY^T . X[M][Kin]
+// Tiles of the two products are interleaved over the chip (gemm256.hip: gemm256pair_kernel).
+extern "C" int csm_gemm_bf16_dgrad_wgrad(const void* dY, const void* W, void* dX, const void* X, void* dW, int M, int Nout, int Kin,
+                                         int ld_dy, int ldw, int ld_dx, int ldx, int ld_dw, int dx_epilogue, const void* aux_in,
+                                         int ld_aux, int accumulate, float alpha_w, hipStream_t stream) {
+    CSM_REQUIRE(dY && W && dX && X && dW, "csm_gemm_bf16_dgrad_wgrad: null operand");
+    CSM_REQUIRE(M > 0 && Nout > 0 && Kin > 0 && M % 64 == 0 && Nout % 64 == 0 && (Kin & 7) == 0,
+                "csm_gemm_bf16_dgrad_wgrad: M and Nout must be multiples of 64, Kin of 8 (M=%d Nout=%d Kin=%d)", M, Nout, Kin);
+    CSM_REQUIRE((ld_dy & 7) == 0 && (ldw & 7) == 0 && (ldx & 7) == 0 && (ld_dw & 7) == 0 && (ld_dx & 7) == 0 && ld_dy >= Nout && ldw >= Kin &&
+                ldx >= Kin && ld_dw >= Kin, "csm_gemm_bf16_dgrad_wgrad: bad leading dimensions");
+    CSM_REQUIRE(((uintptr_t)dY & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)dX & 15) == 0 &&
+                ((uintptr_t)dW & 15) == 0, "csm_gemm_bf16_dgrad_wgrad: operands must be 16-byte aligned");
+    CSM_REQUIRE(dx_epilogue == 0 || dx_epilogue == 2, "csm_gemm_bf16_dgrad_wgrad: dx_epilogue must be 0 or 2");
+    if (dx_epilogue == 2)
+        CSM_REQUIRE(aux_in && (Kin & 3) == 0 && ld_dx >= 2 * Kin && (ld_aux & 7) == 0 && ld_aux >= 2 * Kin && ((uintptr_t)aux_in & 15) == 0,
+                    "csm_gemm_bf16_dgrad_wgrad: bad SwiGLU-backward epilogue arguments");
+    else
+        CSM_REQUIRE(ld_dx >= Kin, "csm_gemm_bf16_dgrad_wgrad: ld_dx too small");
+    return csm_gemm256_pair_launch(dY, W, dX, M, Nout, Kin, ld_dy, ldw, ld_dx, dx_epilogue, aux_in, ld_aux, X, ldx, dW, ld_dw, accumulate,
+                                   alpha_w, stream);
+}

@@ -76,10 +76,8 @@ constexpr bool EARLY_B = CSM_ABLATE & 32;    // flip the layout's default for th
 constexpr bool EARLY_A1 = CSM_ABLATE & 16;   // flip: A1 of the next tile in ph1 instead of with A0 in ph4
 
 template <int TA, int TB, typename OutT>
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const int bz, char* smem) {
     const int nwg = g.tiles_m * g.tiles_n;
-    int id = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
@@ -99,7 +97,6 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     const int tn = (id % per_group) / gsz;
     const int m0 = tm * 256, n0 = tn * 256;
 
-    const int bz = blockIdx.z;
     const bf16_t* A = g.A + (size_t)bz * g.sA;
     const bf16_t* B = g.B + (size_t)bz * g.sB;
     const int lane = threadIdx.x & 63;
@@ -208,6 +205,42 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     }
 }
 
+template <int TA, int TB, typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256_body<TA, TB, OutT>(g, blockIdx.x, blockIdx.z, smem);
+}
+
+// Two independent GEMMs in ONE launch: the dgrad (nn) and the wgrad (tn) of the same Linear layer, which share dY and
+// nothing else.  Their tiles take different times (different K, different epilogues), and the work list interleaves them
+// in blocks of 8 workgroups (one per XCD) in the ratio of their tile counts - so the chip stops marching in lockstep:
+// while some CUs sit in an HBM-bound epilogue (the SwiGLU-backward one reads and writes 512 KB per tile) the others are in
+// their MFMA main loops, instead of all 256 CUs hitting HBM together and then all idling the memory system together.
+// It also fills the chip for wgrads with few tiles (attention projections) without fp32 split-K slabs.
+struct Gemm256Pair {
+    Gemm256Args a, b;         // a: nn (dgrad), b: tn (wgrad); both bf16 out
+    int na, nb;               // tiles of each
+    int ra, rb;               // interleave: ra workgroups of a, then rb of b, ... (multiples of 8)
+};
+
+__global__ __launch_bounds__(512, 2) void gemm256pair_kernel(Gemm256Pair p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // list position -> (kind, index within kind); once one kind runs out the rest of the list is the other kind
+    const int per = p.ra + p.rb;
+    const int full = min(p.na / p.ra, p.nb / p.rb);            // whole interleave periods
+    const int pos = blockIdx.x;
+    int kind, j;
+    if (pos < full * per) {
+        const int q = pos / per, r = pos % per;
+        if (r < p.ra) { kind = 0; j = q * p.ra + r; } else { kind = 1; j = q * p.rb + (r - p.ra); }
+    } else {
+        const int rest = pos - full * per, left_a = p.na - full * p.ra;
+        if (rest < left_a) { kind = 0; j = full * p.ra + rest; } else { kind = 1; j = full * p.rb + (rest - left_a); }
+    }
+    if (kind == 0) gemm256_body<0, 1, bf16_t>(p.a, j, 0, smem);
+    else gemm256_body<1, 1, bf16_t>(p.b, j, 0, smem);
+}
+
 
 template <int TA, int TB>
 int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) {
@@ -245,4 +278,39 @@ int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int
     if (!transA && transB) return launch256<0, 1>(g, out_f32, batch, stream);
     if (transA && transB) return launch256<1, 1>(g, out_f32, batch, stream);
     return launch256<1, 0>(g, out_f32, batch, stream);
+}
+
+static void fill256(Gemm256Args& g, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                    int ldr, float alpha, int epi_mode, const void* aux_in, void* aux_out, int ld_aux) {
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.sA = g.sB = g.sC = g.sR = 0; g.alpha = alpha;
+    g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
+    g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
+    g.epi_p0 = g.epi_p1 = 0;
+}
+
+// dX[M][Kin] = dY[M][Nout] W[Nout][Kin] (epilogue dx_epi: 0 none, 2 SwiGLU backward with aux gu / output d(gu))  together with
+// dW[Nout][Kin] (+)= alpha_w * dY^T X.   Shapes must suit the 256x256 kernel (contractions multiples of 64).
+int csm_gemm256_pair_launch(const void* dY, const void* W, void* dX, int M, int Nout, int Kin, int ld_dy, int ldw, int ld_dx,
+                            int dx_epi, const void* aux_in, int ld_aux,
+                            const void* X, int ldx, void* dW, int ld_dw, int accumulate, float alpha_w, hipStream_t stream) {
+    Gemm256Pair p;
+    // a: C = dY . W  (A = dY [M][Nout] K-contiguous, B = W read as [K = Nout][N = Kin])
+    fill256(p.a, dY, W, dX, nullptr, M, Kin, Nout, ld_dy, ldw, ld_dx, 0, 1.f, dx_epi, aux_in, nullptr, ld_aux);
+    // b: C = dY^T . X  (A = dY read as [K = M][M' = Nout], B = X read as [K = M][N = Kin])
+    fill256(p.b, dY, X, dW, accumulate ? dW : nullptr, Nout, Kin, M, ld_dy, ldx, ld_dw, ld_dw, alpha_w, 0, nullptr, nullptr, 0);
+    p.na = p.a.tiles_m * p.a.tiles_n;
+    p.nb = p.b.tiles_m * p.b.tiles_n;
+    // interleave in blocks of 8 in (roughly) the ratio of the tile counts, longest-running kind first inside a period
+    int ra = 8, rb = 8;
+    if (p.na >= 2 * p.nb) ra = 8 * (int)((p.na + p.nb / 2) / p.nb > 8 ? 8 : (p.na + p.nb / 2) / p.nb);
+    else if (p.nb >= 2 * p.na) rb = 8 * (int)((p.nb + p.na / 2) / p.na > 8 ? 8 : (p.nb + p.na / 2) / p.na);
+    p.ra = ra; p.rb = rb;
+    static bool done = false;
+    const size_t lds = 10 * HALF;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm256pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL(gemm256pair_kernel, dim3(p.na + p.nb), dim3(512), lds, stream, p);
+    CSM_CHECK_LAUNCH("csm_gemm_bf16_dgrad_wgrad");
+    return 0;
 }

@@ -56,6 +56,14 @@ int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M
  * (src/csm/training/utils.py:81-82). */
 int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                        const float* rope_table, int rows_per_seq, int n_rope_cols, int head_dim, csm_stream_t stream);
+/* The two backward products of a Linear layer in one launch, their tiles interleaved over the chip:
+ *   dX[M][Kin] = dY[M][Nout] W[Nout][Kin]   (dx_epilogue 0), or the SwiGLU backward of that product (dx_epilogue 2: W = w2,
+ *   aux_in = gate/up [M][2 Kin], dX = d(gate/up) [M][2 Kin]);   dW[Nout][Kin] (+)= alpha_w * dY^T X[M][Kin].
+ * Replaces autograd's two matmuls per nn.Linear in `loss.backward()` (reference src/csm/training/trainer.py:261-263). */
+int csm_gemm_bf16_dgrad_wgrad(const void* dY, const void* W, void* dX, const void* X, void* dW, int M, int Nout, int Kin, int ld_dy,
+                              int ldw, int ld_dx, int ldx, int ld_dw, int dx_epilogue, const void* aux_in, int ld_aux,
+                              int accumulate, float alpha_w, csm_stream_t stream);
+
 
 
 /* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = the 256x256 pipelined kernel

@@ -192,6 +192,40 @@ def test_rmsnorm(dev, M, D):
     close("rmsnorm dscale", dw, wr.grad, 1e-2)
 
 
+@pytest.mark.parametrize("M,Nout,Kin,swiglu,acc", [(512, 256, 320, False, False), (1024, 2048, 512, False, True), (2048, 256, 512, True, False),
+                                                  (4096, 2048, 2048, False, True), (192, 128, 64, True, True)])
+def test_linear_dx_dw_pair(dev, M, Nout, Kin, swiglu, acc):
+    """csm_gemm_bf16_dgrad_wgrad: dgrad (optionally with the SwiGLU-backward epilogue) and wgrad of a Linear layer in one
+    launch with interleaved tiles - against the two separate launches (same tile kernel: bit-identical) and the oracle."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(M + Nout + Kin)
+    dy = rnd((M, Nout), g, 0.5).to(dev)
+    w = rnd((Nout, Kin), g, 0.1).to(dev)
+    x = rnd((M, Kin), g, 0.5).to(dev)
+    gu = rnd((M, 2 * Kin), g, 1.0).to(dev) if swiglu else None
+    dw0 = rnd((Nout, Kin), g, 0.2).to(dev)
+    # separate launches, 256x256 kernel forced so that the arithmetic order is the paired kernel's
+    ops.lib.csm_set_gemm_variant(3)
+    try:
+        dx_ref = torch.empty(M, 2 * Kin if swiglu else Kin, dtype=BF, device=dev)
+        if swiglu:
+            ops.linear_dx_swiglu_bwd(dy, w, gu, dx_ref)
+        else:
+            ops.linear_dx(dy, w, dx_ref)
+        dw_ref = dw0.clone()
+        ops.gemm(dy, x, dw_ref, dw_ref if acc else None, True, True, 0.5)
+    finally:
+        ops.lib.csm_set_gemm_variant(2)
+    dx = torch.empty_like(dx_ref)
+    dw = dw0.clone()
+    assert ops.linear_dx_dw(dy, w, dx, x, dw, accumulate=acc, alpha=0.5, swiglu_gu=gu)
+    assert torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref), "paired launch must reproduce the separate launches bit for bit"
+    ref_dw = 0.5 * dy.float().t() @ x.float() + (dw0.float() if acc else 0)
+    close("paired dW", dw, ref_dw, 1e-2)
+    if not swiglu:
+        close("paired dX", dx, dy.float() @ w.float(), 1e-2)
+
+
 @pytest.mark.parametrize("M,S,H,KV,hd,K", [(100, 50, 4, 2, 64, 256), (96, 32, 2, 1, 128, 192), (4096, 2048, 32, 8, 64, 2048)])
 def test_linear_rope_fused_epilogue(dev, M, S, H, KV, hd, K):
     """csm_gemm_bf16_rope: the q|k|v projection with RoPE applied to the fp32 accumulators of the q and k columns, against
