@@ -33,55 +33,51 @@ __device__ __forceinline__ ValIdx block_arg(ValIdx x, ValIdx* red) {
 }
 
 // reference src/csm/models/model.py:79-96: logits/T, keep values >= k-th largest, log_softmax -> softmax,
-// argmax(p / q) with q ~ Exp(1) supplied by the caller.  One block per row, V <= 256*16.
+// argmax(p / q) with q ~ Exp(1) supplied by the caller.  One 256-thread block per row, V <= 256 * NPT.
+// The k-th largest value comes from a 32-round bisection on an order-preserving integer image of the floats; a round
+// counts "keys >= trial" with wave ballots + scalar popcounts (no cross-lane shuffles: __shfl_xor is an LDS-crossbar
+// ds_bpermute, six of them per reduction were most of the first version's 26 us) and ONE barrier (the per-wave counts
+// alternate between two LDS slots).  A generated frame draws 32 codes one after the other, so this kernel's latency is
+// paid 32 times per 80 ms of audio.
 constexpr int SMP_PER_THREAD = 16;
+template <int NPT>
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, const float* __restrict__ q,
                                                           int* __restrict__ out, int V, int ldl, int topk, float temperature) {
     __shared__ ValIdx red[4];
     __shared__ float fred[16];
+    __shared__ int cnt_s[2][4];
     const int row = blockIdx.x;
     const float* x = logits + (size_t)row * ldl;
     const float* qq = q + (size_t)row * V;
-    float val[SMP_PER_THREAD];
-    bool removed[SMP_PER_THREAD];
-#pragma unroll
-    for (int j = 0; j < SMP_PER_THREAD; ++j) {
-        const int c = threadIdx.x + 256 * j;
-        val[j] = c < V ? x[c] / temperature : -INFINITY;
-        removed[j] = c >= V;
-    }
-    // k-th largest value (ties count as distinct elements, as in torch.topk) by bisection on an order-preserving integer
-    // image of the floats: 32 rounds of "how many keys are >= trial", each one block-wide count - instead of removing
-    // one maximum per round for k rounds.
-    uint32_t key[SMP_PER_THREAD];
+    const int wave = threadIdx.x >> 6;
+    float val[NPT];
+    uint32_t key[NPT];
     float tmax = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < SMP_PER_THREAD; ++j) {
+    for (int j = 0; j < NPT; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        val[j] = c < V ? x[c] / temperature : -INFINITY;
         const uint32_t u = __float_as_uint(val[j]);
-        key[j] = removed[j] ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+        key[j] = c >= V ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
         tmax = fmaxf(tmax, val[j]);
     }
     const float top = block_max(tmax, fred);
-    __shared__ int cnt_s[4];
     uint32_t prefix = 0u;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t trial = prefix | (1u << bit);
-        int c = 0;
+        int c = 0;                                       // wave-uniform: every ballot is a scalar mask
 #pragma unroll
-        for (int j = 0; j < SMP_PER_THREAD; ++j) c += key[j] >= trial ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        for (int j = 0; j < NPT; ++j) c += __popcll(__ballot(key[j] >= trial));
+        if ((threadIdx.x & 63) == 0) cnt_s[bit & 1][wave] = c;
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) cnt_s[threadIdx.x >> 6] = c;
-        __syncthreads();
-        if (cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3] >= topk) prefix = trial;
+        if (cnt_s[bit & 1][0] + cnt_s[bit & 1][1] + cnt_s[bit & 1][2] + cnt_s[bit & 1][3] >= topk) prefix = trial;
     }
     const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
     const float kth = __uint_as_float(ku);
     // log_softmax over kept values, then softmax of that (torch evaluates both)
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < SMP_PER_THREAD; ++j) {
+    for (int j = 0; j < NPT; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < V && val[j] >= kth) s += expf(val[j] - top);
     }
@@ -90,14 +86,14 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     const float ymax = (top - top) - logsum;
     float s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < SMP_PER_THREAD; ++j) {
+    for (int j = 0; j < NPT; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < V && val[j] >= kth) s2 += expf(((val[j] - top) - logsum) - ymax);
     }
     s2 = block_sum(s2, fred);
     ValIdx best = {-INFINITY, 0x7fffffff};
 #pragma unroll
-    for (int j = 0; j < SMP_PER_THREAD; ++j) {
+    for (int j = 0; j < NPT; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < V) {
             float p = 0.f;
@@ -161,7 +157,8 @@ extern "C" int csm_sample_topk(const float* logits, const float* q, int* out, in
     CSM_REQUIRE(logits && q && out && rows > 0 && V > 0 && ldl >= V, "csm_sample_topk: bad arguments");
     CSM_REQUIRE(V <= 256 * SMP_PER_THREAD, "csm_sample_topk: V=%d exceeds %d", V, 256 * SMP_PER_THREAD);
     CSM_REQUIRE(topk > 0 && topk <= V && temperature > 0.f, "csm_sample_topk: bad topk=%d / temperature=%f", topk, temperature);
-    hipLaunchKernelGGL(sample_topk_kernel, dim3(rows), dim3(256), 0, stream, logits, q, out, V, ldl, topk, temperature);
+    if (V <= 256 * 9) hipLaunchKernelGGL(sample_topk_kernel<9>, dim3(rows), dim3(256), 0, stream, logits, q, out, V, ldl, topk, temperature);
+    else hipLaunchKernelGGL(sample_topk_kernel<SMP_PER_THREAD>, dim3(rows), dim3(256), 0, stream, logits, q, out, V, ldl, topk, temperature);
     CSM_CHECK_LAUNCH("csm_sample_topk");
     return 0;
 }
