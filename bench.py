@@ -110,12 +110,22 @@ class GemmTimer:
             timer.hbm.append(((28 + (2 if zero_grad else 0)) * master.numel(), e0, e1))
             return r
 
+        self.orig_adamw_split = ops.adamw_step_split
+
+        def adamw_split(lo, m, v, param, grad, *args, zero_grad=False, **kw):   # master as bf16 + 16-bit halves: 26 B/param
+            e0, e1 = ev()
+            e0.record(); r = timer.orig_adamw_split(lo, m, v, param, grad, *args, zero_grad=zero_grad, **kw); e1.record()
+            timer.hbm.append(((26 + (2 if zero_grad else 0)) * lo.numel(), e0, e1))
+            return r
+
+        ops.adamw_step_split = adamw_split
         ops.gemm, ops.linear_swiglu_fwd, ops.linear_dx_swiglu_bwd, ops.adamw_step = timed, fused_fwd, fused_bwd, adamw
         return self
 
     def __exit__(self, *a):
         self.ops.gemm, self.ops.linear_swiglu_fwd, self.ops.linear_dx_swiglu_bwd = self.orig, self.orig_fwd, self.orig_bwd
         self.ops.adamw_step = self.orig_adamw
+        self.ops.adamw_step_split = self.orig_adamw_split
         self.ops.linear_rope_fwd = self.orig_rope
 
     def adamw_summary(self):

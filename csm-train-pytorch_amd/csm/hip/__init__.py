@@ -58,6 +58,7 @@ _SIGS = {
     "csm_sumsq_bf16": ([_p, _ll, _p, _p], _i),
     "csm_clip_coef": ([_p, _i, _f, _p, _p], _i),
     "csm_adamw_step": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _i, _p], _i),
+    "csm_adamw_step_split": ([_p, _p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p, _f, _i, _p], _i),
     "csm_set_adamw_blocks": ([_i], _i),
     "csm_gemv_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_gemv_t_bf16": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),

@@ -286,6 +286,14 @@ def adamw_step(master, m, v, param, grad, lr, beta1, beta2, eps, wd, step, norm_
                              beta2, eps, wd, int(step), _ptr(norm_and_coef), float(grad_mul), int(zero_grad), _stream()), "csm_adamw_step")
 
 
+def adamw_step_split(master_lo, m, v, param, grad, lr, beta1, beta2, eps, wd, step, norm_and_coef=None, grad_mul=1.0, zero_grad=False):
+    n = master_lo.numel()
+    assert master_lo.dtype == torch.int16 and param.dtype == BF16 and grad.dtype == BF16 and param.numel() == n == grad.numel()
+    check(lib.csm_adamw_step_split(master_lo.data_ptr(), m.data_ptr(), v.data_ptr(), param.data_ptr(), grad.data_ptr(), n, lr, beta1,
+                                   beta2, eps, wd, int(step), _ptr(norm_and_coef), float(grad_mul), int(zero_grad), _stream()),
+          "csm_adamw_step_split")
+
+
 def gemv(x, W, y, residual=None):
     """y[B,N] = x[B,K] W[N,K]^T (+ residual), B <= 4."""
     B, K = x.shape

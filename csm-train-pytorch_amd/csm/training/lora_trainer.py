@@ -221,7 +221,7 @@ class CSMLoRATrainer:
             for k, dst in names.items():
                 dst.copy_(sd[k].to(device=dst.device, dtype=dst.dtype))
         if self.optimizer is not None and "lora" in self.optimizer.state:
-            self.optimizer.state["lora"]["master"].copy_(self.model.lora.arena.float())
+            self.optimizer.set_master("lora", self.model.lora.arena.float())
 
     def generate_sample(self, text: str, speaker_id: int = 0, output_path: str = "sample.wav") -> str:
         """Reference lora_trainer.py:635-700."""

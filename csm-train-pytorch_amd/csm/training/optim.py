@@ -3,9 +3,15 @@
 
 One launch per learning-rate group (backbone / decoder / embeddings / other - contiguous ranges of the arena, the
 same name-substring routing as the reference) plus one for the LoRA arena; fp32 master weights and moments, bf16
-working copy and gradients: 28 bytes of HBM traffic per parameter and step.  The clip coefficient stays on the
-device and is applied inside the AdamW kernel, so clipping costs one read of the gradients and no host sync.
+working copy and gradients.  The clip coefficient stays on the device and is applied inside the AdamW kernel, so
+clipping costs one read of the gradients and no host sync.
+
+Master weights are fp32 but not stored as such: the bf16 working copy IS the upper half of the master (rounded
+half-up) and a 16-bit ``lo`` tensor holds the lower half, master = ((hi - (lo >> 15)) << 16) | lo exactly - 26 instead of
+28 bytes of HBM traffic per parameter and step and 2 bytes less state (``CSM_ADAMW_SPLIT=0`` restores the plain fp32
+master for A/B).  ``state_dict`` / ``named_master`` still speak fp32 masters, so checkpoints keep their format.
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -13,6 +19,21 @@ import torch
 from ..hip import ops
 
 F32 = torch.float32
+SPLIT_MASTER = os.environ.get("CSM_ADAMW_SPLIT", "1") == "1"
+
+
+def split_master(master: torch.Tensor, param_out: torch.Tensor) -> torch.Tensor:
+    """fp32 master -> bf16 working copy (upper half, rounded half-up, written into ``param_out``) + int16 lower half."""
+    bits = master.contiguous().view(torch.int32)
+    param_out.view(torch.int16).copy_(((bits + 0x8000) >> 16).to(torch.int16))
+    return (bits & 0xFFFF).to(torch.int16)          # values >= 0x8000 wrap to negative int16: same 16 bits
+
+
+def join_master(param: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    """The exact fp32 master from the two halves."""
+    hi = param.view(torch.int16).to(torch.int32) & 0xFFFF
+    l = lo.to(torch.int32) & 0xFFFF
+    return (((hi - (l >> 15)) << 16) | l).view(torch.float32)
 
 
 class FusedAdamW:
@@ -49,7 +70,12 @@ class FusedAdamW:
                     so = v.storage_offset() - base
                     if g["offset"] <= so < g["offset"] + g["numel"]:
                         torch.as_strided(master, v.size(), v.stride(), so - g["offset"]).copy_(t.to(master.device))
-            self.state[g["name"]] = dict(master=master, m=torch.zeros_like(master), v=torch.zeros_like(master))
+            if SPLIT_MASTER:
+                lo = split_master(master, p)          # the working copy becomes the master's (half-up rounded) upper half
+                self.state[g["name"]] = dict(lo=lo, m=torch.zeros_like(master), v=torch.zeros_like(master))
+                del master
+            else:
+                self.state[g["name"]] = dict(master=master, m=torch.zeros_like(master), v=torch.zeros_like(master))
         self._partials = torch.empty(max(1, len(self.param_groups)) * ops.sumsq_blocks(), dtype=F32, device=model.device)
         self._norm_coef = torch.ones(2, dtype=F32, device=model.device)
 
@@ -60,11 +86,28 @@ class FusedAdamW:
         for g in self.param_groups:
             if g["name"] == "lora":
                 continue
-            master = self.state[g["name"]]["master"]
+            master = self.master(g["name"])
             for k, v in views.items():
                 so = v.storage_offset() - base
                 if g["offset"] <= so < g["offset"] + g["numel"]:
                     yield k, torch.as_strided(master, v.size(), v.stride(), so - g["offset"])
+
+    def _group(self, name):
+        return next(g for g in self.param_groups if g["name"] == name)
+
+    def master(self, name: str) -> torch.Tensor:
+        """fp32 master weights of a group (a fresh tensor when the master is stored split)."""
+        st = self.state[name]
+        return st["master"] if "master" in st else join_master(self._group(name)["param"], st["lo"])
+
+    def set_master(self, name: str, master: torch.Tensor):
+        """Overwrite a group's master weights (and with them the bf16 working copy)."""
+        st, g = self.state[name], self._group(name)
+        if "master" in st:
+            st["master"].copy_(master)
+            g["param"].copy_(st["master"])
+        else:
+            st["lo"].copy_(split_master(master.to(device=g["param"].device, dtype=F32), g["param"]))
 
     def num_trainable(self) -> int:
         return sum(g["numel"] for g in self.param_groups)
@@ -109,8 +152,12 @@ class FusedAdamW:
             st = self.state[g["name"]]
             name = g["name"]
             zero = bool(zero_grad) if zero_grad != "lazy" else (name == "embeddings" or name not in gs)
-            ops.adamw_step(st["master"], st["m"], st["v"], g["param"], g["grad"], g["lr"], b1, b2, self.eps,
-                           g["weight_decay"], self.step_count, self._coef, zero_grad=zero)
+            if "lo" in st:
+                ops.adamw_step_split(st["lo"], st["m"], st["v"], g["param"], g["grad"], g["lr"], b1, b2, self.eps,
+                                     g["weight_decay"], self.step_count, self._coef, zero_grad=zero)
+            else:
+                ops.adamw_step(st["master"], st["m"], st["v"], g["param"], g["grad"], g["lr"], b1, b2, self.eps,
+                               g["weight_decay"], self.step_count, self._coef, zero_grad=zero)
             if name in gs:
                 if zero:
                     gs[name] = "zero"
@@ -121,7 +168,8 @@ class FusedAdamW:
     def state_dict(self):
         return {"step": self.step_count,
                 "groups": [{k: g[k] for k in ("name", "lr", "weight_decay", "offset", "numel")} for g in self.param_groups],
-                "state": {n: {k: t.cpu() for k, t in st.items()} for n, st in self.state.items()}}
+                # (fp32 masters whatever the in-memory form: the checkpoint format does not depend on CSM_ADAMW_SPLIT)
+                "state": {n: {"master": self.master(n).cpu(), "m": st["m"].cpu(), "v": st["v"].cpu()} for n, st in self.state.items()}}
 
     def load_state_dict(self, sd):
         """Groups are matched by NAME (backbone / decoder / embeddings / other / lora), never by position: resuming with
@@ -137,8 +185,9 @@ class FusedAdamW:
                 raise ValueError(f"optimizer group {g['name']!r}: saved range {saved['offset']}+{saved['numel']} != {g['offset']}+{g['numel']}")
         self.step_count = sd["step"]
         for n, st in sd["state"].items():
-            for k, t in st.items():
-                self.state[n][k].copy_(t)
+            self.set_master(n, st["master"])
+            self.state[n]["m"].copy_(st["m"])
+            self.state[n]["v"].copy_(st["v"])
         for g in self.param_groups:
             saved = saved_by_name[g["name"]]
             g["lr"], g["weight_decay"] = saved["lr"], saved["weight_decay"]

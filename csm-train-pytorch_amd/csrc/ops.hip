@@ -506,6 +506,19 @@ __global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict
     }
 }
 
+// One element of torch.optim.AdamW (decoupled decay, bias-corrected, eps outside the sqrt ratio).  Floating-point contraction
+// is off so that every kernel that inlines this rounds exactly the same way (csm_adamw_step and csm_adamw_step_split are
+// bit-identical in master / m / v).
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float lr, float beta1, float beta2, float eps,
+                                            float wd, float bc1, float bc2_sqrt) {
+#pragma clang fp contract(off)
+    p = p * (1.f - lr * wd);
+    m = beta1 * m + (1.f - beta1) * g;
+    v = beta2 * v + ((1.f - beta2) * g) * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - (lr / bc1) * (m / denom);
+}
+
 // torch.optim.AdamW over one contiguous parameter range: fp32 master / m / v, bf16 gradient (times the device-side
 // clip coefficient), writes the bf16 working copy.  28 B/param of HBM traffic.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
@@ -527,12 +540,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
         float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float gj = g[j] * coef;
-            p[j] *= (1.f - lr * wd);
-            mm[j] = beta1 * mm[j] + (1.f - beta1) * gj;
-            vv[j] = beta2 * vv[j] + (1.f - beta2) * gj * gj;
-            const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
-            p[j] -= (lr / bc1) * (mm[j] / denom);
+            adam_update(p[j], mm[j], vv[j], g[j] * coef, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
         }
         *reinterpret_cast<float4*>(master + i * 8) = make_float4(p[0], p[1], p[2], p[3]);
         *reinterpret_cast<float4*>(master + i * 8 + 4) = make_float4(p[4], p[5], p[6], p[7]);
@@ -541,6 +549,50 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
         *reinterpret_cast<float4*>(v + i * 8) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         *reinterpret_cast<float4*>(v + i * 8 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
         *reinterpret_cast<U4*>(param + i * 8) = pack8(p);
+        if (zero_grad) *reinterpret_cast<U4*>(grad + i * 8) = (U4){0u, 0u, 0u, 0u};
+    }
+}
+
+// The same update with the fp32 master weight held as TWO 16-bit halves: the bf16 working copy IS the upper half (rounded
+// half-up: hi = (bits + 0x8000) >> 16) and `lo` the lower 16 bits, so master = ((hi - (lo >> 15)) << 16) | lo exactly - no
+// separate 4-byte master to read and write: 26 instead of 28 B/param.  The arithmetic is the fp32 sequence above, bit for
+// bit; the only visible difference is that an exact tie rounds the bf16 working weight away from zero instead of to even.
+__global__ __launch_bounds__(256) void adamw_split_kernel(uint16_t* __restrict__ lo, float* __restrict__ m, float* __restrict__ v,
+                                                          bf16_t* __restrict__ param, bf16_t* __restrict__ grad, long long n,
+                                                          float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                          float bc2_sqrt, const float* __restrict__ coef_ptr, float gmul,
+                                                          int zero_grad) {
+    const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gmul;
+    const long long nvec = n >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float g[8];
+        unpack8(*reinterpret_cast<const U4*>(grad + i * 8), g);
+        const U4 hw = *reinterpret_cast<const U4*>(param + i * 8), lw = *reinterpret_cast<const U4*>(lo + i * 8);
+        float4 m0 = *reinterpret_cast<const float4*>(m + i * 8), m1 = *reinterpret_cast<const float4*>(m + i * 8 + 4);
+        float4 v0 = *reinterpret_cast<const float4*>(v + i * 8), v1 = *reinterpret_cast<const float4*>(v + i * 8 + 4);
+        const uint32_t hww[4] = {hw.x, hw.y, hw.z, hw.w}, lww[4] = {lw.x, lw.y, lw.z, lw.w};
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t h16 = (hww[j >> 1] >> ((j & 1) * 16)) & 0xffffu, l16 = (lww[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+            p[j] = __uint_as_float(((h16 - (l16 >> 15)) << 16) | l16);
+        }
+        float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t ho[4] = {0u, 0u, 0u, 0u}, lout[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            adam_update(p[j], mm[j], vv[j], g[j] * coef, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+            const uint32_t bits = __float_as_uint(p[j]);
+            ho[j >> 1] |= (((bits + 0x8000u) >> 16) & 0xffffu) << ((j & 1) * 16);
+            lout[j >> 1] |= (bits & 0xffffu) << ((j & 1) * 16);
+        }
+        *reinterpret_cast<float4*>(m + i * 8) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<float4*>(m + i * 8 + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+        *reinterpret_cast<float4*>(v + i * 8) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(v + i * 8 + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+        *reinterpret_cast<U4*>(param + i * 8) = (U4){ho[0], ho[1], ho[2], ho[3]};
+        *reinterpret_cast<U4*>(lo + i * 8) = (U4){lout[0], lout[1], lout[2], lout[3]};
         if (zero_grad) *reinterpret_cast<U4*>(grad + i * 8) = (U4){0u, 0u, 0u, 0u};
     }
 }
@@ -756,5 +808,20 @@ extern "C" int csm_adamw_step(float* master, float* m, float* v, void* param, vo
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 3, 256, g_adamw_blocks)), dim3(256), 0, stream, master, m, v, (bf16_t*)param,
                        (bf16_t*)grad, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, norm_and_coef, grad_mul, zero_grad);
     CSM_CHECK_LAUNCH("csm_adamw_step");
+    return 0;
+}
+
+// AdamW with the master weight split into the bf16 working copy (upper half, rounded half-up) and `master_lo` (lower 16
+// bits): same update as csm_adamw_step, 26 B/param.  Replaces optim.AdamW of reference src/csm/training/trainer.py:166-173.
+extern "C" int csm_adamw_step_split(void* master_lo, float* m, float* v, void* param, void* grad, long long n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, const float* norm_and_coef, float grad_mul,
+                                    int zero_grad, hipStream_t stream) {
+    CSM_REQUIRE(master_lo && m && v && param && grad && n > 0 && step >= 1, "csm_adamw_step_split: bad arguments");
+    CSM_REQUIRE((n & 7) == 0, "csm_adamw_step_split: n must be a multiple of 8 (pad the arena)");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_split_kernel, dim3(grid_for(n >> 3, 256, g_adamw_blocks)), dim3(256), 0, stream, (uint16_t*)master_lo, m, v,
+                       (bf16_t*)param, (bf16_t*)grad, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, norm_and_coef, grad_mul, zero_grad);
+    CSM_CHECK_LAUNCH("csm_adamw_step_split");
     return 0;
 }

@@ -145,6 +145,12 @@ int csm_clip_coef(const float* partials, int n_partials, float max_norm, float* 
 int csm_adamw_step(float* master, float* m, float* v, void* param, void* grad, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const float* norm_and_coef /* or NULL */,
                    float grad_mul, int zero_grad /* clear grad in the same pass */, csm_stream_t stream);
+/* the same update with the fp32 master held as two 16-bit halves: `param` (bf16 working copy = upper half, rounded half-up)
+ * and `master_lo` (lower 16 bits); master = ((hi - (lo >> 15)) << 16) | lo exactly.  26 instead of 28 bytes per parameter. */
+int csm_adamw_step_split(void* master_lo, float* m, float* v, void* param, void* grad, long long n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, const float* norm_and_coef, float grad_mul,
+                         int zero_grad, csm_stream_t stream);
+
 int csm_set_adamw_blocks(int blocks); /* tuning switch */
 
 /* ---- K14: sample_topk + _multinomial_sample_one_no_sync (model.py:79-96), Exp(1) noise q supplied ---------------- */

@@ -280,6 +280,24 @@ def test_rope_table_all_positions_matches_fixture():
         assert prod.shape == tab.shape and float((prod - tab).abs().max()) <= 1e-6
 
 
+def test_split_master_roundtrip():
+    """fp32 master <-> (bf16 working copy, 16-bit lower half): exact both ways, working copy = half-up rounding."""
+    from csm.training.optim import join_master, split_master
+    g = torch.Generator().manual_seed(0)
+    m = torch.randn(50000, generator=g) * torch.randn(50000, generator=g).exp()
+    m[:4] = torch.tensor([0.0, -0.0, 1.0, -1.0])
+    b = m.view(torch.int32)
+    b[10:30] = (b[10:30] & ~0xFFFF) | 0x8000                    # exact ties
+    p = torch.empty(50000, dtype=torch.bfloat16)
+    lo = split_master(m, p)
+    assert lo.dtype == torch.int16 and torch.equal(join_master(p, lo).view(torch.int32), m.view(torch.int32))
+    rne = m.to(torch.bfloat16)
+    differs = p.view(torch.int16) != rne.view(torch.int16)
+    ties = (m.view(torch.int32) & 0xFFFF) == 0x8000
+    assert not bool((differs & ~ties).any()), "away from exact ties the working copy is the usual nearest bf16"
+    assert float(((p.float() - m).abs() / m.abs().clamp_min(1e-30)).max()) <= 2.0 ** -8
+
+
 def test_gradsync_bucket_plan_for_model():
     from csm.models.model import Model, ModelArgs
     from csm.training.dp import GradSync

@@ -133,8 +133,10 @@ def test_train_step_full(dev):
         big = g.abs() > 0.2 * g.abs().max()   # where eps=1e-8 and bf16 gradient noise do not matter
         if big.any():
             assert (upd[big] - upd_ref[big]).abs().max().item() < 1e-4, k
-        # the bf16 working copy is the rounded master
-        assert torch.equal(dict(m.named_parameters())[k].detach().float().cpu(), masters[k].to(BF).float().cpu()), k
+        # the bf16 working copy is the rounded master (upper half of the fp32 bits, rounded half-up: optim.py)
+        mb = masters[k].contiguous().view(torch.int32).cpu()
+        want = (((mb + 0x8000) >> 16) & 0xFFFF).to(torch.int16)
+        assert torch.equal(dict(m.named_parameters())[k].detach().contiguous().view(torch.int16).cpu(), want), k
 
 
 def test_post_adamw_parameters_match_fixture(dev):

@@ -192,6 +192,35 @@ def test_rmsnorm(dev, M, D):
     close("rmsnorm dscale", dw, wr.grad, 1e-2)
 
 
+def test_adamw_split_master_is_bit_exact(dev):
+    """csm_adamw_step_split (master = bf16 working copy + 16-bit lower half, 26 B/param) against csm_adamw_step (plain fp32
+    master, 28 B/param): identical master, m and v bits after three steps with clipping; the working copy is the
+    half-up rounding of the master."""
+    from csm.hip import ops
+    from csm.training.optim import join_master, split_master
+    g = torch.Generator().manual_seed(31)
+    n = 8 * 4096
+    master0 = (torch.randn(n, generator=g) * 0.05).to(dev)
+    master0[:64] = master0[:64].to(BF).float()            # some exactly representable values (lo == 0)
+    grads = [(torch.randn(n, generator=g) * (0.3 if i else 3.0)).to(BF).to(dev) for i in range(3)]
+    coef = torch.tensor([2.0, 0.5], device=dev)
+    ma, m1, v1 = master0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pa = torch.empty(n, dtype=BF, device=dev)
+    pb = torch.empty(n, dtype=BF, device=dev)
+    lo, m2, v2 = split_master(master0, pb), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    assert torch.equal(join_master(pb, lo), master0)
+    for step, gr in enumerate(grads, 1):
+        ga, gb = gr.clone(), gr.clone()
+        ops.adamw_step(ma, m1, v1, pa, ga, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, coef, zero_grad=(step == 2))
+        ops.adamw_step_split(lo, m2, v2, pb, gb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, coef, zero_grad=(step == 2))
+        assert torch.equal(join_master(pb, lo).view(torch.int32), ma.view(torch.int32)), step
+        assert torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(ga, gb)
+        bits = ma.view(torch.int32)
+        assert torch.equal(pb.view(torch.int16), (((bits + 0x8000) >> 16) & 0xFFFF).to(torch.int16))
+        assert float((pb.float() - pa.float()).abs().max()) <= float(pa.float().abs().max()) * 2.0 ** -7    # they differ on ties only
+        assert float((pb.view(torch.int16) != pa.view(torch.int16)).float().mean()) < 1e-3
+
+
 @pytest.mark.parametrize("M,Nout,Kin,swiglu,acc", [(512, 256, 320, False, False), (1024, 2048, 512, False, True), (2048, 256, 512, True, False),
                                                   (4096, 2048, 2048, False, True), (192, 128, 64, True, True)])
 def test_linear_dx_dw_pair(dev, M, Nout, Kin, swiglu, acc):
