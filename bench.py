@@ -110,6 +110,18 @@ class GemmTimer:
             timer.hbm.append(((28 + (2 if zero_grad else 0)) * master.numel(), e0, e1))
             return r
 
+        self.orig_two = ops.two_linear_dw
+
+        def two_dw(dy1, x1, dw1, dy2, x2, dw2, accumulate=False, alpha=1.0):       # two weight gradients in one launch
+            e0, e1 = ev()
+            e0.record(); ok = timer.orig_two(dy1, x1, dw1, dy2, x2, dw2, accumulate=accumulate, alpha=alpha); e1.record()
+            if ok:
+                M = dy1.shape[0]
+                fl = 2.0 * M * (dw1.numel() + dw2.numel())
+                timer.records.append(("tn_wgrad_bf16", fl, e0, e1, 2.0 * (dy1.numel() + x1.numel() + dy2.numel() + x2.numel() + dw1.numel() + dw2.numel())))
+            return ok
+
+        ops.two_linear_dw = two_dw
         self.orig_adamw_split = ops.adamw_step_split
 
         def adamw_split(lo, m, v, param, grad, *args, zero_grad=False, **kw):   # master as bf16 + 16-bit halves: 26 B/param
@@ -126,6 +138,7 @@ class GemmTimer:
         self.ops.gemm, self.ops.linear_swiglu_fwd, self.ops.linear_dx_swiglu_bwd = self.orig, self.orig_fwd, self.orig_bwd
         self.ops.adamw_step = self.orig_adamw
         self.ops.adamw_step_split = self.orig_adamw_split
+        self.ops.two_linear_dw = self.orig_two
         self.ops.linear_rope_fwd = self.orig_rope
 
     def adamw_summary(self):

@@ -32,6 +32,9 @@ FUSE_ROPE_FWD = _os.environ.get("CSM_FUSE_ROPE_FWD", "1") == "1"      # A/B swit
 # launches (73.7 ms/step -> 75.7 with w2 alone, 77.4 w13, 77.1 output_proj, 78.3 qkv, 83.2 all four): de-phasing the CUs'
 # epilogues does not pay for two operand sets competing for each XCD's 4 MiB L2.  Kept as a tested entry point.
 PAIR_DX_DW = int(_os.environ.get("CSM_PAIR_DX_DW", "0"))
+# A/B switch: the two small weight gradients of a layer (attention output projection: 64 tiles, fused q|k|v: 96 tiles of
+# 256x256) as ONE launch after the attention backward, instead of split-K slabs + column sum and a 128x128-tile launch
+GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
 
 
 class _Stack:
@@ -190,11 +193,14 @@ class _Stack:
             dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx)   # + residual path
             # ---- attention: h = x + output_proj(o)
             do = torch.empty(M, H * hd, dtype=BF16, device=dev)
+            group_dw = False
             if not (train_base and (PAIR_DX_DW & 4) and ops.linear_dx_dw(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do, a["o"],
                                                                         self.w(f"layers.{i}.attn.output_proj.weight", True),
                                                                         accumulate=acc, alpha=alpha)):
                 ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
-                if train_base:
+                # (the output projection's dW waits for the q|k|v projection's below when the two can share one launch)
+                group_dw = train_base and GROUP_ATTN_DW and not (PAIR_DX_DW & 8) and M % 64 == 0 and M >= 4096 and c.embed_dim >= 2048
+                if train_base and not group_dw:
                     ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
             ad = self._lora(i, "output_proj")
             if ad is not None:
@@ -209,7 +215,12 @@ class _Stack:
             if not (train_base and (PAIR_DX_DW & 8) and ops.linear_dx_dw(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn, a["xn"],
                                                                         self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)):
                 ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
-                if train_base:
+                if train_base and group_dw and ops.two_linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), dh, a["o"],
+                                                                 self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha):
+                    pass
+                elif train_base:
+                    if group_dw:
+                        ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
                     ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)
             for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
                 ad = self._lora(i, mod)

@@ -103,6 +103,20 @@ def linear_dx_dw(dy, w, dx, x, dw, accumulate=False, alpha=1.0, swiglu_gu=None):
     return True
 
 
+def two_linear_dw(dy1, x1, dw1, dy2, x2, dw2, accumulate=False, alpha=1.0):
+    """dw1[N1,K1] (+)= alpha dy1^T x1 and dw2[N2,K2] (+)= alpha dy2^T x2 (same row count M) in ONE launch of 256x256 tiles.
+    Returns False when the shapes do not suit it (caller falls back to two linear_dw calls)."""
+    M = dy1.shape[0]
+    ts = (dy1, x1, dw1, dy2, x2, dw2)
+    if M % 64 or dy2.shape[0] != M or any(t.stride(1) != 1 for t in ts) or any(d % 8 for t in ts for d in t.shape[1:]):
+        return False
+    assert x1.shape[0] == M and x2.shape[0] == M and dw1.shape == (dy1.shape[1], x1.shape[1]) and dw2.shape == (dy2.shape[1], x2.shape[1])
+    check(lib.csm_gemm_bf16_two_wgrad(dy1.data_ptr(), x1.data_ptr(), dw1.data_ptr(), dy1.shape[1], x1.shape[1], dy1.stride(0), x1.stride(0),
+                                      dw1.stride(0), dy2.data_ptr(), x2.data_ptr(), dw2.data_ptr(), dy2.shape[1], x2.shape[1], dy2.stride(0),
+                                      x2.stride(0), dw2.stride(0), M, int(accumulate), float(alpha), _stream()), "csm_gemm_bf16_two_wgrad")
+    return True
+
+
 _splitk_ws = {}
 
 

@@ -268,3 +268,23 @@ extern "C" int csm_gemm_bf16_dgrad_wgrad(const void* dY, const void* W, void* dX
     return csm_gemm256_pair_launch(dY, W, dX, M, Nout, Kin, ld_dy, ldw, ld_dx, dx_epilogue, aux_in, ld_aux, X, ldx, dW, ld_dw, accumulate,
                                    alpha_w, stream);
 }
+
+int csm_gemm256_two_wgrad_launch(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
+                                 const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
+                                 int M, int accumulate, float alpha, hipStream_t stream);
+
+// Two weight gradients that share the token dimension M, in ONE launch of 256x256 tiles (autograd's dW = dY^T X of two
+// nn.Linear layers; reference loop src/csm/training/trainer.py:261-263).  For outputs too small to fill 256 CUs alone.
+extern "C" int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
+                                       const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
+                                       int M, int accumulate, float alpha, hipStream_t stream) {
+    CSM_REQUIRE(dY1 && X1 && dW1 && dY2 && X2 && dW2, "csm_gemm_bf16_two_wgrad: null operand");
+    CSM_REQUIRE(M > 0 && M % 64 == 0 && N1 > 0 && N2 > 0 && K1 > 0 && K2 > 0 && ((N1 | N2 | K1 | K2) & 7) == 0,
+                "csm_gemm_bf16_two_wgrad: M must be a multiple of 64, the other dimensions of 8");
+    CSM_REQUIRE(((ld_dy1 | ldx1 | ld_dw1 | ld_dy2 | ldx2 | ld_dw2) & 7) == 0 && ld_dy1 >= N1 && ldx1 >= K1 && ld_dw1 >= K1 && ld_dy2 >= N2 &&
+                ldx2 >= K2 && ld_dw2 >= K2, "csm_gemm_bf16_two_wgrad: bad leading dimensions");
+    CSM_REQUIRE((((uintptr_t)dY1 | (uintptr_t)X1 | (uintptr_t)dW1 | (uintptr_t)dY2 | (uintptr_t)X2 | (uintptr_t)dW2) & 15) == 0,
+                "csm_gemm_bf16_two_wgrad: operands must be 16-byte aligned");
+    return csm_gemm256_two_wgrad_launch(dY1, X1, dW1, N1, K1, ld_dy1, ldx1, ld_dw1, dY2, X2, dW2, N2, K2, ld_dy2, ldx2, ld_dw2, M,
+                                        accumulate, alpha, stream);
+}

@@ -260,6 +260,18 @@ int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) 
     return 0;
 }
 
+// Two weight-gradient products (tn, bf16 out) in one launch: neither fills the chip alone (attention output projection:
+// 64 tiles, fused q|k|v projection: 96 tiles on 256 CUs), together they are one round of 160 tiles - instead of a
+// 128x128-tile launch at 0.7-0.8 PF/s plus fp32 split-K slabs and a column-sum pass.
+struct Gemm256Two { Gemm256Args a, b; int na; };
+__global__ __launch_bounds__(512, 2) void gemm256two_tn_kernel(Gemm256Two p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int id = blockIdx.x;
+    // longest first is moot (same K); keep each problem's tiles contiguous so that an XCD's L2 sees one operand set at a time
+    if (id < p.na) gemm256_body<1, 1, bf16_t>(p.a, id, 0, smem);
+    else gemm256_body<1, 1, bf16_t>(p.b, id - p.na, 0, smem);
+}
+
 }  // namespace
 
 // called by csm_gemm_bf16 (gemm.hip) when the tile heuristic picks the 256x256 kernel; same argument meaning
@@ -312,5 +324,22 @@ int csm_gemm256_pair_launch(const void* dY, const void* W, void* dX, int M, int 
     if (!done) { (void)hipFuncSetAttribute((const void*)gemm256pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
     hipLaunchKernelGGL(gemm256pair_kernel, dim3(p.na + p.nb), dim3(512), lds, stream, p);
     CSM_CHECK_LAUNCH("csm_gemm_bf16_dgrad_wgrad");
+    return 0;
+}
+
+// dW1[N1][K1] (+)= alpha dY1[M][N1]^T X1[M][K1]  and  dW2[N2][K2] (+)= alpha dY2[M][N2]^T X2[M][K2]  in one launch
+int csm_gemm256_two_wgrad_launch(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
+                                 const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
+                                 int M, int accumulate, float alpha, hipStream_t stream) {
+    Gemm256Two p;
+    fill256(p.a, dY1, X1, dW1, accumulate ? dW1 : nullptr, N1, K1, M, ld_dy1, ldx1, ld_dw1, ld_dw1, alpha, 0, nullptr, nullptr, 0);
+    fill256(p.b, dY2, X2, dW2, accumulate ? dW2 : nullptr, N2, K2, M, ld_dy2, ldx2, ld_dw2, ld_dw2, alpha, 0, nullptr, nullptr, 0);
+    p.na = p.a.tiles_m * p.a.tiles_n;
+    const int nb = p.b.tiles_m * p.b.tiles_n;
+    static bool done = false;
+    const size_t lds = 10 * HALF;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm256two_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    hipLaunchKernelGGL(gemm256two_tn_kernel, dim3(p.na + nb), dim3(512), lds, stream, p);
+    CSM_CHECK_LAUNCH("csm_gemm_bf16_two_wgrad");
     return 0;
 }

@@ -63,6 +63,12 @@ int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int 
 int csm_gemm_bf16_dgrad_wgrad(const void* dY, const void* W, void* dX, const void* X, void* dW, int M, int Nout, int Kin, int ld_dy,
                               int ldw, int ld_dx, int ldx, int ld_dw, int dx_epilogue, const void* aux_in, int ld_aux,
                               int accumulate, float alpha_w, csm_stream_t stream);
+/* Two weight gradients sharing the token dimension, dW_i[N_i][K_i] (+)= alpha * dY_i[M][N_i]^T X_i[M][K_i], in one launch (for
+ * outputs too small to fill the chip alone: attention output projection + fused q|k|v projection of one layer). */
+int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
+                            const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
+                            int M, int accumulate, float alpha, csm_stream_t stream);
+
 
 
 

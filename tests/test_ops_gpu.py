@@ -192,6 +192,30 @@ def test_rmsnorm(dev, M, D):
     close("rmsnorm dscale", dw, wr.grad, 1e-2)
 
 
+@pytest.mark.parametrize("acc", [False, True])
+def test_two_linear_dw_grouped(dev, acc):
+    """csm_gemm_bf16_two_wgrad: two weight gradients of different output shapes in one launch = the two separate launches of
+    the same tile kernel, bit for bit."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(77)
+    M = 1024
+    dy1, x1 = rnd((M, 768), g, 0.5).to(dev), rnd((M, 512), g, 0.5).to(dev)
+    dy2, x2 = rnd((M, 512), g, 0.5).to(dev), rnd((M, 320), g, 0.5).to(dev)
+    w1, w2 = rnd((768, 512), g, 0.1).to(dev), rnd((512, 320), g, 0.1).to(dev)
+    r1, r2 = w1.clone(), w2.clone()
+    ops.lib.csm_set_gemm_variant(3)
+    try:
+        ops.gemm(dy1, x1, r1, r1 if acc else None, True, True, 0.25)
+        ops.gemm(dy2, x2, r2, r2 if acc else None, True, True, 0.25)
+    finally:
+        ops.lib.csm_set_gemm_variant(2)
+    assert ops.two_linear_dw(dy1, x1, w1, dy2, x2, w2, accumulate=acc, alpha=0.25)
+    assert torch.equal(w1, r1) and torch.equal(w2, r2)
+    if not acc:
+        close("grouped dW1", w1, 0.25 * dy1.float().t() @ x1.float(), 1e-2)
+        close("grouped dW2", w2, 0.25 * dy2.float().t() @ x2.float(), 1e-2)
+
+
 def test_adamw_split_master_is_bit_exact(dev):
     """csm_adamw_step_split (master = bf16 working copy + 16-bit lower half, 26 B/param) against csm_adamw_step (plain fp32
     master, 28 B/param): identical master, m and v bits after three steps with clipping; the working copy is the
