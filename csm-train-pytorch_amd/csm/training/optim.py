@@ -185,9 +185,11 @@ class FusedAdamW:
                 raise ValueError(f"optimizer group {g['name']!r}: saved range {saved['offset']}+{saved['numel']} != {g['offset']}+{g['numel']}")
         self.step_count = sd["step"]
         for n, st in sd["state"].items():
-            self.set_master(n, st["master"])
-            self.state[n]["m"].copy_(st["m"])
-            self.state[n]["v"].copy_(st["v"])
+            for k, v in st.items():
+                if k == "master":
+                    self.set_master(n, v)
+                else:
+                    self.state[n][k].copy_(v)
         for g in self.param_groups:
             saved = saved_by_name[g["name"]]
             g["lr"], g["weight_decay"] = saved["lr"], saved["weight_decay"]

@@ -21,6 +21,8 @@ def load(path, counter):
 
 
 def kind(name):
+    if name.startswith("gemm256two_tn_kernel"):      # two bf16 weight gradients in one launch
+        return "tn_wgrad_bf16"
     m = re.match(r"gemm(256p|256s|256)?_kernel<(\d), (\d), (u16|float)", name)
     if not m:
         return None
