@@ -118,13 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
     e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N; e.p0 = g.epi_p0; e.p1 = g.epi_p1;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm0 + 16 * i + (lane & 15);
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp)
-            epi_store_pair<OutT>(e, vec_ok, m, n0 + wn0 + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
-    }
+    epi_block<OutT, 4>(e, vec_ok, m0 + wm0, n0 + wn0, lane, acc);
 }
 
 int g_gemm_variant = 2;   // 0 register staging, 1 LDS-DMA 128x128, 2 auto (256x256 where it fills the chip), 3 force 256x256

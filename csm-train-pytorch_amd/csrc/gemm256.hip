@@ -196,13 +196,7 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
             return;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + 16 * i + (lane & 15);
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp)
-            epi_store_pair<OutT>(e, vec_ok, m, n0 + wc * 64 + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
-    }
+    epi_block<OutT, 8>(e, vec_ok, m0 + wr * 128, n0 + wc * 64, lane, acc);
 }
 
 template <int TA, int TB, typename OutT>

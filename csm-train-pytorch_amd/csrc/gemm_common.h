@@ -248,29 +248,35 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
 // SwiGLU-backward epilogue for a wave's NI x NJ block of 16x16 accumulators (rows mb + 16 i, d(act) columns nb + 16 j):
 // the gate/up vectors of TWO accumulator rows (2 * NJ 16-byte loads per lane) are fetched before any of their results is
 // stored - issued one by one between the stores they would sit behind every store's address check and the epilogue
-// would pay one full memory latency per accumulator.
+// would pay one full memory latency per accumulator.  The loads of the next row pair are issued before this pair's
+// arithmetic and stores (two register buffers), so the memory system always has this wave's reads queued.
 template <int NI, int NJ>
 __device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int nb, int lane, const f32x4 (&acc)[NI][NJ]) {
     const int g = lane >> 4;
     bf16_t* C = reinterpret_cast<bf16_t*>(e.C);
-#pragma unroll
-    for (int i = 0; i < NI; i += 2) {
-        U4 gu[2][NJ];
+    U4 gu[2][2][NJ];                     // [buffer][row of the pair][j]: the NEXT row pair is in flight while this one is worked on
+    auto fetch = [&](int i, U4 (&dst)[2][NJ]) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int m = mb + 16 * (i + ii) + (lane & 15), n = nb + 16 * j + 4 * g;
-                gu[ii][j] = (U4){0u, 0u, 0u, 0u};
-                if (m < e.M && n < e.N) gu[ii][j] = *reinterpret_cast<const U4*>(e.aux_in + (size_t)m * e.ld_aux + 2 * n);
+                // (lanes outside the matrix read a clamped, valid address and never store: no branch between the loads)
+                const int m = min(mb + 16 * (i + ii) + (lane & 15), e.M - 1), n = min(nb + 16 * j + 4 * g, e.N - 4);
+                dst[ii][j] = *reinterpret_cast<const U4*>(e.aux_in + (size_t)m * e.ld_aux + 2 * n);
             }
+    };
+    fetch(0, gu[0]);
+#pragma unroll
+    for (int i = 0; i < NI; i += 2) {
+        if (i + 2 < NI) fetch(i + 2, gu[((i >> 1) + 1) & 1]);
+        const U4 (&cur)[2][NJ] = gu[(i >> 1) & 1];
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int m = mb + 16 * (i + ii) + (lane & 15), n = nb + 16 * j + 4 * g;
                 float gv[8], o[8];
-                unpack8(gu[ii][j], gv);
+                unpack8(cur[ii][j], gv);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = acc[i + ii][j][k] * e.alpha, gt = gv[2 * k], up = gv[2 * k + 1];
@@ -326,6 +332,124 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
         for (int k = 0; k < 4; ++k) a[k] = v[2 * k] / (1.f + __expf(-v[2 * k])) * v[2 * k + 1];
         uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
         *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
+    }
+}
+
+// A wave's NI x 4 grid of 16x16 accumulators (rows mb + 16 i, columns nb .. nb+63).  When every 16-byte access of the block
+// is legal (uniform test) the block takes the fast path: everything it READS - the residual rows, the RoPE table entries -
+// is requested up front (residual) or two rows ahead (RoPE table), never between two stores.  Read one by one, as the
+// per-pair form does, each of the 2 NI reads costs a full memory round trip before its store can go (R may alias C, so
+// the compiler cannot hoist them itself): 16 serial round trips per wave in the 256x256 kernel, whose epilogue no other
+// workgroup on the CU overlaps.
+template <typename OutT, int NI>
+__device__ __forceinline__ void epi_block(const Epi& e, bool vec_ok, int mb, int nb, int lane, const f32x4 (&acc)[NI][4]) {
+    bool fast = false;
+    if constexpr (sizeof(OutT) == 2)
+        fast = vec_ok && (e.mode == EPI_NONE || (e.mode == EPI_ROPE && (e.p0 & 63) == 0 && (e.p1 & 7) == 0) ||
+                          (e.mode == EPI_SWIGLU_FWD && (e.ld_aux & 3) == 0)) &&
+               (e.ldc & 7) == 0 && (!e.R || (e.ldr & 7) == 0) && nb + 63 < e.N && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) &&
+               (!e.R || (reinterpret_cast<uintptr_t>(e.R) & 15) == 0);
+    if (!fast) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = mb + 16 * i + (lane & 15);
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) epi_store_pair<OutT>(e, vec_ok, m, nb + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
+        }
+        return;
+    }
+    if constexpr (sizeof(OutT) == 2) {
+        const int g = lane >> 4;
+        const int nl = nb + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);      // this lane's 8 columns of pair jp start at nl + 32 jp
+        const int ml = mb + (lane & 15);                               // this lane's row of accumulator row i is ml + 16 i
+        bf16_t* C = reinterpret_cast<bf16_t*>(e.C);
+        // permlane swap of one accumulator pair -> this lane's 8 consecutive columns, scaled
+        auto gather = [&](int i, int jp, float (&v)[8]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * jp][k]), __float_as_uint(acc[i][2 * jp + 1][k]), false, false);
+                v[k] = __uint_as_float(r[0]) * e.alpha;
+                v[4 + k] = __uint_as_float(r[1]) * e.alpha;
+            }
+        };
+        if (e.mode == EPI_ROPE && nb < e.p0) {
+            // ---- rotated columns (q, k heads): table entries two rows ahead; a residual (LoRA up-projection), rare here, inline
+            float4 cs[2][2][2][2];                                      // [buffer][row of the pair][jp][half]: (c, s) of 2 pairs each
+            auto rope_fetch = [&](int i, float4 (&dst)[2][2][2]) {
+                const float* table = reinterpret_cast<const float*>(e.aux_in);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const int pos = (ml + 16 * (i + ii)) % e.ld_aux, n = nl + 32 * jp;
+                        const float* t = table + ((size_t)pos * (e.p1 >> 1) + ((n % e.p1) >> 1)) * 2;
+                        dst[ii][jp][0] = *reinterpret_cast<const float4*>(t);
+                        dst[ii][jp][1] = *reinterpret_cast<const float4*>(t + 4);
+                    }
+            };
+            rope_fetch(0, cs[0]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if ((i & 1) == 0 && i + 2 < NI) rope_fetch(i + 2, cs[((i >> 1) + 1) & 1]);
+                const int m = ml + 16 * i;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    float v[8];
+                    gather(i, jp, v);
+                    const int n = nl + 32 * jp;
+                    if (e.R && m < e.M) {
+                        float f[8];
+                        unpack8(*reinterpret_cast<const U4*>(e.R + (size_t)m * e.ldr + n), f);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += f[k];
+                    }
+                    const float4 (&q)[2] = cs[(i >> 1) & 1][i & 1][jp];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {                       // pairs (4h, 4h+1) and (4h+2, 4h+3)
+                        const float a0 = v[4 * h] * q[h].x - v[4 * h + 1] * q[h].y, a1 = v[4 * h + 1] * q[h].x + v[4 * h] * q[h].y;
+                        const float a2 = v[4 * h + 2] * q[h].z - v[4 * h + 3] * q[h].w, a3 = v[4 * h + 3] * q[h].z + v[4 * h + 2] * q[h].w;
+                        v[4 * h] = a0; v[4 * h + 1] = a1; v[4 * h + 2] = a2; v[4 * h + 3] = a3;
+                    }
+                    if (m < e.M) *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + n) = pack8(v);
+                }
+            }
+            return;
+        }
+        // ---- everything else: all residual rows of the block first
+        U4 rr[NI][2];
+        if (e.R) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp)      // rows past M read row M-1 (never stored): no branch between the loads
+                    rr[i][jp] = *reinterpret_cast<const U4*>(e.R + (size_t)min(ml + 16 * i, e.M - 1) * e.ldr + nl + 32 * jp);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = ml + 16 * i;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float v[8];
+                gather(i, jp, v);
+                if (e.R) {
+                    float f[8];
+                    unpack8(rr[i][jp], f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += f[k];
+                }
+                const int n = nl + 32 * jp;
+                if (m < e.M) {
+                    *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + n) = pack8(v);
+                    if (e.mode == EPI_SWIGLU_FWD) {
+                        float a[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = v[2 * k] / (1.f + __expf(-v[2 * k])) * v[2 * k + 1];
+                        uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
+                        *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
+                    }
+                }
+            }
+        }
     }
 }
 
