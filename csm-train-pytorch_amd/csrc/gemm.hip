@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         }
     }
 
+    if (g.kx) k_extend<4>(g.xA, g.xB, g.kx, g.M, g.N, m0 + wm0, n0 + wn0, lane, acc);
+
     // ---- epilogue: lane owns C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] per 16x16 tile ----------
     Epi e;
     e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
@@ -144,7 +146,7 @@ int launch(const GemmArgs& g, int out_f32, int batch, hipStream_t stream) {
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                        int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
                        long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
-                       hipStream_t stream, int epi_p0 = 0, int epi_p1 = 0);
+                       hipStream_t stream, int epi_p0 = 0, int epi_p1 = 0, const void* xA = nullptr, const void* xB = nullptr, int kx = 0);
 
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
@@ -170,7 +172,8 @@ extern "C" int csm_set_gemm_variant(int v) {
 static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
                          int ldb, int ldc, int ldr, int transA, int transB, int out_f32, float alpha, int batch,
                          long long strideA, long long strideB, long long strideC, long long strideR, int epilogue,
-                         const void* aux_in, void* aux_out, int ld_aux, hipStream_t stream, int epi_p0, int epi_p1) {
+                         const void* aux_in, void* aux_out, int ld_aux, hipStream_t stream, int epi_p0, int epi_p1,
+                         const void* xA = nullptr, const void* xB = nullptr, int kx = 0) {
     CSM_REQUIRE(A && B && C, "csm_gemm_bf16: null operand");
     CSM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "csm_gemm_bf16: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     CSM_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "csm_gemm_bf16: lda/ldb must be multiples of 8 (lda=%d ldb=%d)", lda, ldb);
@@ -188,9 +191,10 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, i
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 3 && K % 64 == 0 && M >= 8 && N >= 8))
         return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
-                                  strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1);
+                                  strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1, xA, xB, kx);
     GemmArgs g;
     g.epi_p0 = epi_p0; g.epi_p1 = epi_p1;
+    g.xA = (const bf16_t*)xA; g.xB = (const bf16_t*)xB; g.kx = kx;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sR = strideR;
@@ -223,6 +227,26 @@ extern "C" int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, 
                 "csm_gemm_bf16_rope: bad arguments");
     return gemm_dispatch(A, W, C, nullptr, M, N, K, lda, ldw, ldc, 0, 0, 0, 0, 1.f, 1, 0, 0, 0, 0, EPI_ROPE, rope_table, nullptr,
                          rows_per_seq, stream, n_rope_cols, head_dim);
+}
+
+// A frozen projection and its LoRA adapters as ONE product (reference LoRALinear.__call__, src/csm/mlx/components/lora.py:85-105:
+// y = x W0^T + scale * (x A^T) B^T; the same for the input gradient dx = dy W0 + scale * (dy B) A):
+//   C[M][N] = A . B  (operand layouts by transA / transB as in csm_gemm_bf16)  +  xA[M][kx] . xB[N][kx]^T   (+ R)
+// xA / xB are row-major with leading dimension kx (a multiple of 32; adapter ranks padded with zeros), bf16, 16-byte
+// aligned; the extra k-steps run after the main loop, in fp32, in the same accumulators, before the epilogue.
+// epilogue: 0 none, 1 SwiGLU forward (aux_out, ld_aux as in csm_gemm_bf16_ex), 3 RoPE (aux_in = table, ld_aux = rows per
+// sequence, rope_cols, head_dim as in csm_gemm_bf16_rope).
+extern "C" int csm_gemm_bf16_kext(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                                  int ldr, int transA, int transB, const void* xA, const void* xB, int kx, int epilogue,
+                                  const void* aux_in, void* aux_out, int ld_aux, int rope_cols, int head_dim, hipStream_t stream) {
+    CSM_REQUIRE(xA && xB && kx > 0 && kx % 32 == 0 && kx <= 256, "csm_gemm_bf16_kext: kx must be a multiple of 32 in [32, 256] (kx=%d)", kx);
+    CSM_REQUIRE(((uintptr_t)xA & 15) == 0 && ((uintptr_t)xB & 15) == 0, "csm_gemm_bf16_kext: xA / xB must be 16-byte aligned");
+    CSM_REQUIRE(epilogue == 0 || epilogue == 1 || epilogue == 3, "csm_gemm_bf16_kext: epilogue must be 0, 1 or 3");
+    if (epilogue == 3)
+        CSM_REQUIRE(aux_in && ld_aux > 0 && head_dim >= 8 && (head_dim & 7) == 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % head_dim == 0 &&
+                    (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && !transA && !transB, "csm_gemm_bf16_kext: bad RoPE epilogue arguments");
+    return gemm_dispatch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, 0, 1.f, 1, 0, 0, 0, 0, epilogue, aux_in, aux_out, ld_aux,
+                         stream, epilogue == 3 ? rope_cols : 0, epilogue == 3 ? head_dim : 0, xA, xB, kx);
 }
 
 extern "C" int csm_gemm_bf16(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,

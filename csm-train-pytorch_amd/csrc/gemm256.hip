@@ -24,6 +24,7 @@ struct Gemm256Args {
     int tiles_m, tiles_n;
     int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
     int epi_p0, epi_p1;
+    const bf16_t* xA; const bf16_t* xB; int kx;      // K-extension operands (gemm_common.h: k_extend)
 };
 
 // one 16-KiB half-tile by LDS-DMA: 16 pieces of 1 KiB over 8 waves
@@ -184,6 +185,8 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     }
 #undef MFMA_PAIR
 
+    if (g.kx) k_extend<8>(g.xA, g.xB, g.kx, g.M, g.N, m0 + wr * 128, n0 + wc * 64, lane, acc);
+
     Epi e;
     e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
     e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
@@ -272,9 +275,10 @@ __global__ __launch_bounds__(512, 2) void gemm256two_tn_kernel(Gemm256Two p) {
 int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                        int ldr, int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB,
                        long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
-                       hipStream_t stream, int epi_p0, int epi_p1) {
+                       hipStream_t stream, int epi_p0, int epi_p1, const void* xA, const void* xB, int kx) {
     Gemm256Args g;
     g.epi_p0 = epi_p0; g.epi_p1 = epi_p1;
+    g.xA = (const bf16_t*)xA; g.xB = (const bf16_t*)xB; g.kx = kx;
     g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
@@ -291,6 +295,7 @@ static void fill256(Gemm256Args& g, const void* A, const void* B, void* C, const
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sA = g.sB = g.sC = g.sR = 0; g.alpha = alpha;
+    g.xA = g.xB = nullptr; g.kx = 0;
     g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
     g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.epi_p0 = g.epi_p1 = 0;

@@ -19,6 +19,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
     int epi_p0, epi_p1;   // EPI_ROPE: columns [0, p0) are rotated, head_dim p1
+    const bf16_t* xA; const bf16_t* xB; int kx;   // K-extension (see k_extend): C += xA[M][kx] . xB[N][kx]^T, kx % 32 == 0, 0 = none
 };
 
 // ---- staging: each thread moves 4 x 16 B per operand per K-tile --------------------------------
@@ -450,6 +451,31 @@ __device__ __forceinline__ void epi_block(const Epi& e, bool vec_ok, int mb, int
                 }
             }
         }
+    }
+}
+
+// K-extension: after the main loop, kx / 32 more MFMA k-steps whose operands come straight from global memory - xA [M][kx]
+// and xB [N][kx], both row-major with leading dimension kx (64-byte rows per k-step: one 16-byte load per lane and
+// fragment, 16 rows x 64 contiguous bytes per instruction).  This is how a LoRA adapter joins the frozen projection's
+// GEMM: y = x W0^T + (s x A^T) B^T is one product over K + r with xA = s x A^T (padded to 32 columns) and xB = B (reference
+// src/csm/mlx/components/lora.py:85-105), accumulated in fp32 in the same accumulators, before any epilogue - no second
+// pass over y, and epilogues that must see the sum (RoPE, SwiGLU) stay fused.  Same for dx = dy W0 + (s dy B) A.
+template <int NI>
+__device__ __forceinline__ void k_extend(const bf16_t* __restrict__ xA, const bf16_t* __restrict__ xB, int kx, int M, int N, int mb,
+                                         int nb, int lane, f32x4 (&acc)[NI][4]) {
+    const int c = (lane >> 4) * 8;
+    for (int k0 = 0; k0 < kx; k0 += 32) {
+        bf16x8 fa[NI], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fb[j] = *reinterpret_cast<const bf16x8*>(xB + (size_t)min(nb + 16 * j + (lane & 15), N - 1) * kx + k0 + c);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            fa[i] = *reinterpret_cast<const bf16x8*>(xA + (size_t)min(mb + 16 * i + (lane & 15), M - 1) * kx + k0 + c);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
 }
 

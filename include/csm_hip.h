@@ -56,6 +56,16 @@ int csm_gemm_bf16_ex(const void* A, const void* B, void* C, const void* R, int M
  * (src/csm/training/utils.py:81-82). */
 int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                        const float* rope_table, int rows_per_seq, int n_rope_cols, int head_dim, csm_stream_t stream);
+/* A frozen projection and its LoRA adapters as ONE product: C[M][N] = A . B (layouts by transA / transB as in csm_gemm_bf16)
+ * + xA[M][kx] . xB[N][kx]^T (+ R), the extra kx / 32 k-steps taken after the main loop, in fp32, in the same accumulators,
+ * before the epilogue (0 none; 1 SwiGLU forward: aux_out / ld_aux as in csm_gemm_bf16_ex; 3 RoPE: aux_in = table, ld_aux =
+ * rows per sequence, rope_cols / head_dim as in csm_gemm_bf16_rope).  xA / xB: bf16, row-major, leading dimension kx (a
+ * multiple of 32, <= 256; ranks padded with zeros), 16-byte aligned.  Replaces the two extra matmuls and the add of
+ * LoRALinear.__call__ (reference src/csm/mlx/components/lora.py:85-105: y = x W0^T + scale (x A^T) B^T, with xA = scale x A^T
+ * and xB = B) and of its input gradient (dx = dy W0 + (scale dy B) A: xA = scale dy B, xB = A^T). */
+int csm_gemm_bf16_kext(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
+                       int transA, int transB, const void* xA, const void* xB, int kx, int epilogue, const void* aux_in,
+                       void* aux_out, int ld_aux, int rope_cols, int head_dim, csm_stream_t stream);
 /* The two backward products of a Linear layer in one launch, their tiles interleaved over the chip:
  *   dX[M][Kin] = dY[M][Nout] W[Nout][Kin]   (dx_epilogue 0), or the SwiGLU backward of that product (dx_epilogue 2: W = w2,
  *   aux_in = gate/up [M][2 Kin], dX = d(gate/up) [M][2 Kin]);   dW[Nout][Kin] (+)= alpha_w * dY^T X[M][Kin].

@@ -303,6 +303,56 @@ def test_linear_rope_fused_epilogue(dev, M, S, H, KV, hd, K):
     assert torch.equal(out[:, (H + KV) * hd:], plain[:, (H + KV) * hd:]), "v columns must be the plain projection"
 
 
+@pytest.mark.parametrize("M,N,K,kx,transB,epi", [
+    (100, 72, 64, 32, False, "none"),          # ragged edges, 128x128 kernel, narrow epilogue path
+    (300, 256, 192, 64, True, "none"),         # nn (input-gradient form), two extension k-steps, residual
+    (4096, 3072, 2048, 32, False, "rope"),     # the q|k|v projection of the backbone: 128x128 kernel, RoPE epilogue on the sum
+    (8192, 2048, 3072, 32, True, "none"),      # the backbone's q|k|v input gradient: 256x256 kernel, residual
+    (2048, 4096, 512, 32, False, "swiglu"),    # SwiGLU epilogue on the sum (256x256 kernel)
+])
+def test_gemm_k_extension(dev, M, N, K, kx, transB, epi):
+    """csm_gemm_bf16_kext: C = A.B + xA.xB^T (+R) with the extension's k-steps taken inside the same product - a frozen
+    projection plus its LoRA adapters (reference LoRALinear.__call__, src/csm/mlx/components/lora.py:85-105) - against the
+    fp32 reference of the sum; the epilogues (RoPE, SwiGLU) must see the sum."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(M + N + kx)
+    a = rnd((M, K), g, 0.5 if K < 1024 else 0.25)
+    b = rnd((K, N) if transB else (N, K), g, 0.1)
+    xa = torch.zeros(M, kx, dtype=BF)
+    xb = torch.zeros(N, kx, dtype=BF)
+    r = kx - 8                                   # the padding columns stay zero, as adapter ranks below the pad width do
+    xa[:, :r] = rnd((M, r), g, 0.5)
+    xb[:, :r] = rnd((N, r), g, 0.2)
+    y = a.float() @ (b.float() if transB else b.float().t()) + xa.float() @ xb.float().t()
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    if epi == "rope":
+        H, KV, hd, S = 32, 8, 64, 2048
+        table = O.rope_table(S, hd)
+        pos = (torch.arange(M) % S).view(1, M)
+        ref = y.clone()
+        ref[:, :H * hd] = O.rope(y[:, :H * hd].reshape(1, M, H, hd), table, pos).reshape(M, -1)
+        ref[:, H * hd:(H + KV) * hd] = O.rope(y[:, H * hd:(H + KV) * hd].reshape(1, M, KV, hd), table, pos).reshape(M, -1)
+        ops.gemm_kext(a.to(dev), b.to(dev), out, xa.to(dev), xb.to(dev), rope=(table.to(dev), S, (H + KV) * hd, hd))
+        close("k-extension + rope", out, ref, 1.5e-2)
+    elif epi == "swiglu":
+        act = torch.empty(M, N // 2, dtype=BF, device=dev)
+        ops.gemm_kext(a.to(dev), b.to(dev), out, xa.to(dev), xb.to(dev), swiglu_act=act)
+        close("k-extension gate/up", out, y, 1e-2)
+        yb = out.float().cpu()
+        close("k-extension silu(gate)*up", act, torch.nn.functional.silu(yb[:, 0::2]) * yb[:, 1::2], 1e-2)
+    else:
+        res = rnd((M, N), g, 1.0) if transB else None
+        ops.gemm_kext(a.to(dev), b.to(dev), out, xa.to(dev), xb.to(dev), R=None if res is None else res.to(dev), transB=transB)
+        close("k-extension", out, y + (res.float() if res is not None else 0), 1e-2)
+    # all-zero extension operands reproduce the plain product bit for bit
+    plain = torch.empty(M, N, dtype=BF, device=dev)
+    if epi == "none" and not transB:
+        ops.gemm(a.to(dev), b.to(dev), plain)
+        z = torch.empty(M, N, dtype=BF, device=dev)
+        ops.gemm_kext(a.to(dev), b.to(dev), z, torch.zeros(M, kx, dtype=BF, device=dev), torch.zeros(N, kx, dtype=BF, device=dev))
+        assert torch.equal(z, plain)
+
+
 @pytest.mark.parametrize("hd,H,KV", [(64, 4, 2), (128, 2, 1)])
 def test_rope(dev, hd, H, KV):
     from csm.hip import ops
