@@ -122,6 +122,18 @@ class GemmTimer:
             return ok
 
         ops.two_linear_dw = two_dw
+        self.orig_kext = ops.gemm_kext
+
+        def kext(A, B, C, xA, xB, R=None, transB=False, **kw):        # frozen projection + LoRA group in one product
+            e0, e1 = ev()
+            e0.record(); r = timer.orig_kext(A, B, C, xA, xB, R=R, transB=transB, **kw); e1.record()
+            M, K = A.shape
+            N = B.shape[1] if transB else B.shape[0]
+            timer.records.append(("nn_dgrad_bf16" if transB else "nt_fwd_bf16", 2.0 * M * N * (K + xA.shape[1]), e0, e1,
+                                  2.0 * (M * K + N * K + C.numel() + xA.numel() + xB.numel())))
+            return r
+
+        ops.gemm_kext = kext
         self.orig_adamw_split = ops.adamw_step_split
 
         def adamw_split(lo, m, v, param, grad, *args, zero_grad=False, **kw):   # master as bf16 + 16-bit halves: 26 B/param
@@ -139,6 +151,7 @@ class GemmTimer:
         self.ops.adamw_step = self.orig_adamw
         self.ops.adamw_step_split = self.orig_adamw_split
         self.ops.two_linear_dw = self.orig_two
+        self.ops.gemm_kext = self.orig_kext
         self.ops.linear_rope_fwd = self.orig_rope
 
     def adamw_summary(self):

@@ -35,6 +35,8 @@ PAIR_DX_DW = int(_os.environ.get("CSM_PAIR_DX_DW", "0"))
 # A/B switch: the two small weight gradients of a layer (attention output projection: 64 tiles, fused q|k|v: 96 tiles of
 # 256x256) as ONE launch after the attention backward, instead of split-K slabs + column sum and a 128x128-tile launch
 GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
+# LoRA groups ride on the frozen projections' GEMMs as K-extension operands (training/lora.py); 0 = per-adapter products
+LORA_FUSE = _os.environ.get("CSM_LORA_FUSE", "1") != "0"
 
 
 class _Stack:
@@ -52,6 +54,13 @@ class _Stack:
         lo = self.m.lora
         return lo.get(self.prefix, layer, module) if lo is not None else None
 
+    def _group(self, layer: int, gname: str):
+        """(group, fused?) - the LoRA adapters of ``layer`` on one fused projection (lora.py GROUPS); fused = the whole
+        group enters that projection's GEMMs as one K-extension operand pair."""
+        lo = self.m.lora
+        G = lo.group(self.prefix, layer, gname) if lo is not None else None
+        return G, (G is not None and LORA_FUSE and G.fusable())
+
     # -------------------------------------------------------------------------------------------- forward
     def forward(self, x: torch.Tensor, B: int, S: int, save: bool, pos: Optional[torch.Tensor] = None,
                 fuse_rope: bool = True) -> torch.Tensor:
@@ -67,9 +76,18 @@ class _Stack:
             ops.rmsnorm_fwd(x, self.w(f"layers.{i}.sa_norm.scale"), xn, rstd1, c.norm_eps)
             qkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
             hq, hk = H * hd, KV * hd
-            if FUSE_ROPE_FWD and fuse_rope and pos is None and not any(self._lora(i, mod) is not None for mod in ("q_proj", "k_proj", "v_proj")):
+            G, fused = self._group(i, "attn_in")
+            rope_in_gemm = FUSE_ROPE_FWD and fuse_rope and pos is None
+            if G is None and rope_in_gemm:
                 # positions = arange(S) and nothing to add before the rotation: RoPE rides in the projection's epilogue
                 ops.linear_rope_fwd(xn, self.w(f"layers.{i}.attn.qkv"), qkv, table, S, hq + hk, hd)
+            elif fused:
+                # the adapters' up-projections are extra k-steps of the same product, so the rotation still sees the sum
+                a["tx_attn_in"] = G.project(xn)
+                ops.gemm_kext(xn, self.w(f"layers.{i}.attn.qkv"), qkv, a["tx_attn_in"], G.Bx,
+                              rope=(table, S, hq + hk, hd) if rope_in_gemm else None)
+                if not rope_in_gemm:
+                    ops.rope(qkv, table, S, H + KV, hd, pos=pos)
             else:
                 ops.linear_fwd(xn, self.w(f"layers.{i}.attn.qkv"), qkv)
                 for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
@@ -81,30 +99,37 @@ class _Stack:
             lse = torch.empty(B, H, S, dtype=F32, device=dev)
             ops.attn_fwd(qkv, o, lse, B, S, H, KV, hd)
             h = torch.empty(M, d, dtype=BF16, device=dev)
-            ops.linear_fwd(o, self.w(f"layers.{i}.attn.output_proj.weight"), h, residual=x)
-            ad = self._lora(i, "output_proj")
-            if ad is not None:
-                a["t_output_proj"] = ad.forward(o, h)
+            G, fused = self._group(i, "attn_out")
+            if fused:
+                a["tx_attn_out"] = G.project(o)
+                ops.gemm_kext(o, self.w(f"layers.{i}.attn.output_proj.weight"), h, a["tx_attn_out"], G.Bx, R=x)
+            else:
+                ops.linear_fwd(o, self.w(f"layers.{i}.attn.output_proj.weight"), h, residual=x)
+                ad = self._lora(i, "output_proj")
+                if ad is not None:
+                    a["t_output_proj"] = ad.forward(o, h)
             hn = torch.empty(M, d, dtype=BF16, device=dev)
             rstd2 = torch.empty(M, dtype=F32, device=dev)
             ops.rmsnorm_fwd(h, self.w(f"layers.{i}.mlp_norm.scale"), hn, rstd2, c.norm_eps)
             gu = torch.empty(M, 2 * F, dtype=BF16, device=dev)     # gate/up interleaved: g0,u0,g1,u1,...
             act = torch.empty(M, F, dtype=BF16, device=dev)
             ad1, ad3 = self._lora(i, "w1"), self._lora(i, "w3")
-            if FUSE_SWIGLU and ad1 is None and ad3 is None:
+            G, fused = self._group(i, "mlp_in")
+            if FUSE_SWIGLU and G is None:
                 ops.linear_swiglu_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu, act)   # activation fused into the GEMM epilogue
+            elif FUSE_SWIGLU and fused:
+                # adapters on w1 / w3: extra k-steps of the w13 product (Bx rows interleaved like w13), SwiGLU from the sum
+                a["tx_mlp_in"] = G.project(hn)
+                ops.gemm_kext(hn, self.w(f"layers.{i}.mlp.w13"), gu, a["tx_mlp_in"], G.Bx, swiglu_act=act)
             elif FUSE_SWIGLU and not any(ad is not None and ad.bias is not None for ad in (ad1, ad3)):
-                # LoRA on w1 / w3 without leaving the fused path: the adapters' (alpha/r) t B^T is written FIRST, for both
-                # at once - t13 = [t1 | t3], B13 = B1 / B3 rows interleaved like w13 (block diagonal) - and the frozen
-                # product takes it in through the residual port of its SwiGLU epilogue: gate/up = acc + R, act from the sum
+                # (dropout: one mask per adapter) the adapters' (alpha/r) t B^T is written FIRST, for both at once -
+                # t13 = the adapters' projections side by side, as the group's Bx expects them - and the frozen product takes it
+                # in through the residual port of its SwiGLU epilogue: gate/up = acc + R, act from the sum
                 rp = (ad1 or ad3).r
-                t13 = torch.zeros(M, 2 * rp, dtype=BF16, device=dev)
-                B13 = torch.zeros(2 * F, 2 * rp, dtype=BF16, device=dev)
-                for mod, col, ad in (("w1", 0, ad1), ("w3", 1, ad3)):
-                    if ad is not None:
-                        a[f"t_{mod}"] = ad.project(hn, t13[:, col * rp:(col + 1) * rp])
-                        B13[col::2, col * rp:(col + 1) * rp] = ad.B
-                ops.gemm(t13, B13, gu, None, alpha=(ad1 or ad3).scaling)
+                t13 = torch.zeros(M, G.kx, dtype=BF16, device=dev)
+                for j, (mod, ad) in enumerate(G.adapters.items()):
+                    a[f"t_{mod}"] = ad.project(hn, t13[:, j * rp:(j + 1) * rp])
+                ops.gemm(t13, G.Bx, gu, None, alpha=(ad1 or ad3).scaling)
                 ops.linear_swiglu_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu, act, residual=gu)
             else:
                 ops.linear_fwd(hn, self.w(f"layers.{i}.mlp.w13"), gu)
@@ -117,10 +142,15 @@ class _Stack:
                             gv[:, :, col] += tmp
                 ops.swiglu_fwd(gu, act)
             out = torch.empty(M, d, dtype=BF16, device=dev)
-            ops.linear_fwd(act, self.w(f"layers.{i}.mlp.w2.weight"), out, residual=h)
-            ad = self._lora(i, "w2")
-            if ad is not None:
-                a["t_w2"] = ad.forward(act, out)
+            G, fused = self._group(i, "mlp_out")
+            if fused:
+                a["tx_mlp_out"] = G.project(act)
+                ops.gemm_kext(act, self.w(f"layers.{i}.mlp.w2.weight"), out, a["tx_mlp_out"], G.Bx, R=h)
+            else:
+                ops.linear_fwd(act, self.w(f"layers.{i}.mlp.w2.weight"), out, residual=h)
+                ad = self._lora(i, "w2")
+                if ad is not None:
+                    a["t_w2"] = ad.forward(act, out)
             if save:
                 a.update(x=x, xn=xn, rstd1=rstd1, qkv=qkv, o=o, lse=lse, h=h, hn=hn, rstd2=rstd2, gu=gu, act=act)
                 self.acts.append(a)
@@ -161,6 +191,8 @@ class _Stack:
             # ---- MLP: out = h + w2(act)
             dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
             ad = self._lora(i, "w2")
+            G, fused = self._group(i, "mlp_out")
+            fused = fused and "tx_mlp_out" in a
             w2_done = False
             if FUSE_SWIGLU and ad is None and train_base and (PAIR_DX_DW & 1):
                 # dgrad (with the SwiGLU backward in its epilogue) and wgrad of w2 share dx and nothing else: one launch
@@ -170,41 +202,65 @@ class _Stack:
                 pass
             elif FUSE_SWIGLU and ad is None:
                 ops.linear_dx_swiglu_bwd(dx, self.w(f"layers.{i}.mlp.w2.weight"), a["gu"], dgu)   # d(act) never stored
+            elif FUSE_SWIGLU and fused:
+                # d(act) = dx w2 + (s dx Bx) At^T inside one product, SwiGLU backward in its epilogue
+                dts = G.backward(a["act"], dx, a["tx_mlp_out"])
+                ops.gemm_kext(dx, self.w(f"layers.{i}.mlp.w2.weight"), dgu, dts, G.At, transB=True, swiglu_bwd_gu=a["gu"])
             else:
                 dact = torch.empty(M, F, dtype=BF16, device=dev)
-                ops.linear_dx(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact)
-                if ad is not None:
-                    ad.backward(a["act"], dx, a["t_w2"], dact)
+                if fused:
+                    dts = G.backward(a["act"], dx, a["tx_mlp_out"])
+                    ops.gemm_kext(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact, dts, G.At, transB=True)
+                else:
+                    ops.linear_dx(dx, self.w(f"layers.{i}.mlp.w2.weight"), dact)
+                    if ad is not None:
+                        ad.backward(a["act"], dx, a["t_w2"], dact)
                 ops.swiglu_bwd(a["gu"], dact, dgu)
                 del dact
             if train_base and not w2_done:
                 ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=acc, alpha=alpha)
             dhn = torch.empty(M, d, dtype=BF16, device=dev)
-            if not (train_base and (PAIR_DX_DW & 2) and ops.linear_dx_dw(dgu, self.w(f"layers.{i}.mlp.w13"), dhn, a["hn"],
-                                                                        self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)):
-                ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
+            G, fused = self._group(i, "mlp_in")
+            fused = fused and "tx_mlp_in" in a
+            if fused:
+                dts = G.backward(a["hn"], dgu, a["tx_mlp_in"])
+                ops.gemm_kext(dgu, self.w(f"layers.{i}.mlp.w13"), dhn, dts, G.At, transB=True)
                 if train_base:
                     ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)
-            for mod, col in (("w1", 0), ("w3", 1)):
-                ad = self._lora(i, mod)
-                if ad is not None:
-                    ad.backward(a["hn"], dgu.view(M, F, 2)[:, :, col].contiguous(), a[f"t_{mod}"], dhn)
+            else:
+                if not (train_base and (PAIR_DX_DW & 2) and ops.linear_dx_dw(dgu, self.w(f"layers.{i}.mlp.w13"), dhn, a["hn"],
+                                                                            self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)):
+                    ops.linear_dx(dgu, self.w(f"layers.{i}.mlp.w13"), dhn)
+                    if train_base:
+                        ops.linear_dw(dgu, a["hn"], self.w(f"layers.{i}.mlp.w13", True), accumulate=acc, alpha=alpha)
+                for mod, col in (("w1", 0), ("w3", 1)):
+                    ad = self._lora(i, mod)
+                    if ad is not None:
+                        ad.backward(a["hn"], dgu.view(M, F, 2)[:, :, col].contiguous(), a[f"t_{mod}"], dhn)
             del dgu
             dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx)   # + residual path
             # ---- attention: h = x + output_proj(o)
             do = torch.empty(M, H * hd, dtype=BF16, device=dev)
             group_dw = False
-            if not (train_base and (PAIR_DX_DW & 4) and ops.linear_dx_dw(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do, a["o"],
-                                                                        self.w(f"layers.{i}.attn.output_proj.weight", True),
-                                                                        accumulate=acc, alpha=alpha)):
-                ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
-                # (the output projection's dW waits for the q|k|v projection's below when the two can share one launch)
-                group_dw = train_base and GROUP_ATTN_DW and not (PAIR_DX_DW & 8) and M % 64 == 0 and M >= 4096 and c.embed_dim >= 2048
-                if train_base and not group_dw:
+            G, fused = self._group(i, "attn_out")
+            fused = fused and "tx_attn_out" in a
+            if fused:
+                dts = G.backward(a["o"], dh, a["tx_attn_out"])
+                ops.gemm_kext(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do, dts, G.At, transB=True)
+                if train_base:
                     ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
-            ad = self._lora(i, "output_proj")
-            if ad is not None:
-                ad.backward(a["o"], dh, a["t_output_proj"], do)
+            else:
+                if not (train_base and (PAIR_DX_DW & 4) and ops.linear_dx_dw(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do, a["o"],
+                                                                            self.w(f"layers.{i}.attn.output_proj.weight", True),
+                                                                            accumulate=acc, alpha=alpha)):
+                    ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
+                    # (the output projection's dW waits for the q|k|v projection's below when the two can share one launch)
+                    group_dw = train_base and GROUP_ATTN_DW and not (PAIR_DX_DW & 8) and M % 64 == 0 and M >= 4096 and c.embed_dim >= 2048
+                    if train_base and not group_dw:
+                        ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
+                ad = self._lora(i, "output_proj")
+                if ad is not None:
+                    ad.backward(a["o"], dh, a["t_output_proj"], do)
             dqkv = torch.empty(M, c.qkv_dim, dtype=BF16, device=dev)
             if pos is None and FUSE_ROPE_BWD:     # positions = arange(S): the RoPE backward rides in the dQ / dK epilogues
                 ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd, rope_table=table)
@@ -212,20 +268,30 @@ class _Stack:
                 ops.attn_bwd(a["qkv"], a["o"], do, a["lse"], dqkv, delta, B, S, H, KV, hd)
                 ops.rope(dqkv, table, S, H + KV, hd, pos=pos, inverse=True)
             dxn = torch.empty(M, d, dtype=BF16, device=dev)
-            if not (train_base and (PAIR_DX_DW & 8) and ops.linear_dx_dw(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn, a["xn"],
-                                                                        self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)):
-                ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
-                if train_base and group_dw and ops.two_linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), dh, a["o"],
-                                                                 self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha):
-                    pass
-                elif train_base:
+            G, fused = self._group(i, "attn_in")
+            fused = fused and "tx_attn_in" in a
+            if fused:
+                dts = G.backward(a["xn"], dqkv, a["tx_attn_in"])
+                ops.gemm_kext(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn, dts, G.At, transB=True)
+                if train_base:
                     if group_dw:
                         ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
                     ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)
-            for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
-                ad = self._lora(i, mod)
-                if ad is not None:
-                    ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
+            else:
+                if not (train_base and (PAIR_DX_DW & 8) and ops.linear_dx_dw(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn, a["xn"],
+                                                                            self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)):
+                    ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
+                    if train_base and group_dw and ops.two_linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), dh, a["o"],
+                                                                     self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha):
+                        pass
+                    elif train_base:
+                        if group_dw:
+                            ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
+                        ops.linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)
+                for mod, lo_, hi_ in (("q_proj", 0, hq), ("k_proj", hq, hq + hk), ("v_proj", hq + hk, hq + 2 * hk)):
+                    ad = self._lora(i, mod)
+                    if ad is not None:
+                        ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
             dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh)
             self.acts[i] = None
             if on_layer_done is not None:

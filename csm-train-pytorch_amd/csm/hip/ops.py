@@ -76,16 +76,17 @@ def linear_rope_fwd(x, w, out, table, S, n_rope_cols, head_dim):
     return out
 
 
-def gemm_kext(A, B, C, xA, xB, R=None, transB=False, rope=None, swiglu_act=None):
+def gemm_kext(A, B, C, xA, xB, R=None, transB=False, rope=None, swiglu_act=None, swiglu_bwd_gu=None):
     """C[M,N] = A . opB(B)^T + xA[M,kx] . xB[N,kx]^T (+ R): a frozen projection with its LoRA adapters as extra k-steps of the
-    same product.  ``rope`` = (table, S, n_rope_cols, head_dim) or ``swiglu_act`` = act[M,N/2] select the fused epilogues."""
+    same product.  ``rope`` = (table, S, n_rope_cols, head_dim), ``swiglu_act`` = act[M,N/2] or ``swiglu_bwd_gu`` = gate/up [M,2N]
+    (then C = d(gate/up) [M,2N]) select the fused epilogues, which see the sum."""
     pa, M, K, lda = _mat(A)
     pb, b0, b1, ldb = _mat(B)
     N, Kb = (b1, b0) if transB else (b0, b1)
     assert K == Kb, (A.shape, B.shape, transB)
     kx = xA.shape[1]
     assert xA.shape == (M, kx) and xB.shape == (N, kx) and xA.is_contiguous() and xB.is_contiguous() and xA.dtype == BF16 and xB.dtype == BF16
-    assert C.shape == (M, N) and C.dtype == BF16 and C.stride(1) == 1
+    assert C.shape == (M, 2 * N if swiglu_bwd_gu is not None else N) and C.dtype == BF16 and C.stride(1) == 1
     pr, ldr = (None, 0) if R is None else (R.data_ptr(), R.stride(0))
     assert R is None or (R.shape == (M, N) and R.stride(1) == 1 and R.dtype == BF16)
     epi, aux_in, aux_out, ld_aux, rc, hd = 0, None, None, 0, 0, 0
@@ -96,6 +97,9 @@ def gemm_kext(A, B, C, xA, xB, R=None, transB=False, rope=None, swiglu_act=None)
     elif swiglu_act is not None:
         assert swiglu_act.shape == (M, N // 2) and swiglu_act.is_contiguous() and C.is_contiguous()
         epi, aux_out, ld_aux = 1, swiglu_act.data_ptr(), N // 2
+    elif swiglu_bwd_gu is not None:      # the product is d(act) [M,N]; C = d(gate/up) [M,2N] from gate/up [M,2N]
+        assert swiglu_bwd_gu.shape == (M, 2 * N) and swiglu_bwd_gu.is_contiguous() and C.is_contiguous() and R is None
+        epi, aux_in, ld_aux = 2, swiglu_bwd_gu.data_ptr(), 2 * N
     check(lib.csm_gemm_bf16_kext(pa, pb, C.data_ptr(), pr, M, N, K, lda, ldb, C.stride(0), ldr, 0, int(transB), xA.data_ptr(),
                                  xB.data_ptr(), kx, epi, aux_in, aux_out, ld_aux, rc, hd, _stream()), "csm_gemm_bf16_kext")
     return C

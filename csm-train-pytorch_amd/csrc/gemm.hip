@@ -234,14 +234,14 @@ extern "C" int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, 
 //   C[M][N] = A . B  (operand layouts by transA / transB as in csm_gemm_bf16)  +  xA[M][kx] . xB[N][kx]^T   (+ R)
 // xA / xB are row-major with leading dimension kx (a multiple of 32; adapter ranks padded with zeros), bf16, 16-byte
 // aligned; the extra k-steps run after the main loop, in fp32, in the same accumulators, before the epilogue.
-// epilogue: 0 none, 1 SwiGLU forward (aux_out, ld_aux as in csm_gemm_bf16_ex), 3 RoPE (aux_in = table, ld_aux = rows per
-// sequence, rope_cols, head_dim as in csm_gemm_bf16_rope).
+// epilogue: 0 none, 1 / 2 SwiGLU forward / backward (aux_out / aux_in, ld_aux as in csm_gemm_bf16_ex), 3 RoPE (aux_in = table,
+// ld_aux = rows per sequence, rope_cols, head_dim as in csm_gemm_bf16_rope).
 extern "C" int csm_gemm_bf16_kext(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
                                   int ldr, int transA, int transB, const void* xA, const void* xB, int kx, int epilogue,
                                   const void* aux_in, void* aux_out, int ld_aux, int rope_cols, int head_dim, hipStream_t stream) {
     CSM_REQUIRE(xA && xB && kx > 0 && kx % 32 == 0 && kx <= 256, "csm_gemm_bf16_kext: kx must be a multiple of 32 in [32, 256] (kx=%d)", kx);
     CSM_REQUIRE(((uintptr_t)xA & 15) == 0 && ((uintptr_t)xB & 15) == 0, "csm_gemm_bf16_kext: xA / xB must be 16-byte aligned");
-    CSM_REQUIRE(epilogue == 0 || epilogue == 1 || epilogue == 3, "csm_gemm_bf16_kext: epilogue must be 0, 1 or 3");
+    CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_kext: epilogue must be 0..3");
     if (epilogue == 3)
         CSM_REQUIRE(aux_in && ld_aux > 0 && head_dim >= 8 && (head_dim & 7) == 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % head_dim == 0 &&
                     (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && !transA && !transB, "csm_gemm_bf16_kext: bad RoPE epilogue arguments");

@@ -58,7 +58,7 @@ int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int 
                        const float* rope_table, int rows_per_seq, int n_rope_cols, int head_dim, csm_stream_t stream);
 /* A frozen projection and its LoRA adapters as ONE product: C[M][N] = A . B (layouts by transA / transB as in csm_gemm_bf16)
  * + xA[M][kx] . xB[N][kx]^T (+ R), the extra kx / 32 k-steps taken after the main loop, in fp32, in the same accumulators,
- * before the epilogue (0 none; 1 SwiGLU forward: aux_out / ld_aux as in csm_gemm_bf16_ex; 3 RoPE: aux_in = table, ld_aux =
+ * before the epilogue (0 none; 1 / 2 SwiGLU forward / backward: aux_out / aux_in, ld_aux as in csm_gemm_bf16_ex; 3 RoPE: aux_in = table, ld_aux =
  * rows per sequence, rope_cols / head_dim as in csm_gemm_bf16_rope).  xA / xB: bf16, row-major, leading dimension kx (a
  * multiple of 32, <= 256; ranks padded with zeros), 16-byte aligned.  Replaces the two extra matmuls and the add of
  * LoRALinear.__call__ (reference src/csm/mlx/components/lora.py:85-105: y = x W0^T + scale (x A^T) B^T, with xA = scale x A^T

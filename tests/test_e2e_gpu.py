@@ -296,6 +296,54 @@ def test_lora_step(dev):
     assert rel(after, before) < 2e-3
 
 
+def test_lora_fused_groups_match_per_adapter_path_and_oracle(dev):
+    """Adapters on all seven projections: the grouped path (one K-extension operand pair per fused projection, RoPE and
+    SwiGLU epilogues on the sum, csm_gemm_bf16_kext) against the per-adapter products on the same storage and against the
+    oracle's LoRALinear restatement (reference lora.py:85-105)."""
+    import csm.engine as E
+    from csm.training.lora import apply_lora_to_model
+    from csm.training.utils import compute_loss
+    mods = ["q_proj", "k_proj", "v_proj", "output_proj", "w1", "w2", "w3"]
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=16)
+    res = {}
+    for fuse in (True, False):
+        m, p32, pq = tiny_model(dev)
+        m.acoustic_mode = "all"
+        apply_lora_to_model(m, r=4, alpha=8.0, target_modules=mods, seed=11)
+        with torch.no_grad():
+            g = torch.Generator(device=dev).manual_seed(12)
+            for ad in m.lora.adapters.values():
+                ad.B[:, :4].copy_((torch.randn(ad.B.shape[0], 4, generator=g, device=dev) * 0.05).to(BF))
+        old = E.LORA_FUSE
+        E.LORA_FUSE = fuse
+        try:
+            total, _ = compute_loss(m, tokens, mask, targets)
+            total.backward()
+        finally:
+            E.LORA_FUSE = old
+        res[fuse] = (float(total), m.lora.grad_arena.float().clone(), m)
+    (tf, gf, m), (tu, gu, _) = res[True], res[False]
+    assert abs(tf - tu) <= 2e-3 * abs(tu), (tf, tu)
+    scale = gu.abs().max().item()
+    assert (gf - gu).abs().max().item() <= 4e-2 * scale, ((gf - gu).abs().max().item(), scale)
+    lora = {k: v.detach().float().cpu().requires_grad_(True) for k, v in m.get_lora_params().items()}
+    rt, _ = O.compute_loss(pq, TINY, tokens, mask, targets, acoustic_rows=None, lora=lora, lora_scaling=2.0)
+    rt.backward()
+    assert rel(torch.tensor(tf), rt) < 1e-3, (tf, float(rt))
+    for ad in m.lora.adapters.values():
+        gclose(f"{ad.name}.lora_A grad", ad.gA[:4], lora[f"{ad.name}.lora_A"].grad, 5e-2)
+        gclose(f"{ad.name}.lora_B grad", ad.gB[:, :4], lora[f"{ad.name}.lora_B"].grad, 5e-2)
+    # nothing outside the adapters' blocks of a group's Bx / At may move: their gradients are exactly zero
+    for G in m.lora.groups.values():
+        if G.mask is not None:
+            assert float((G.gBx.float() * (1 - G.mask.float())).abs().max()) == 0.0, G.name
+        used = len(G.adapters) * m.lora.r_pad
+        assert float(G.gAt[:, used:].abs().max() if used < G.kx else 0.0) == 0.0 and float(G.gBx[:, used:].abs().max() if used < G.kx else 0.0) == 0.0
+        for j in range(len(G.adapters)):
+            c0 = j * m.lora.r_pad
+            assert float(G.gAt[:, c0 + 4:c0 + 8].abs().max()) == 0.0 and float(G.gBx[:, c0 + 4:c0 + 8].abs().max()) == 0.0, "rank padding"
+
+
 def test_lora_rank4_mlp_adapters_and_trainer_step(dev, tmp_path):
     """Row a9 + the r = 4 case the reference documents: ``CSMLoRATrainer.train_step`` (loss -> gradients of the LoRA
     parameters only -> clip g * max_norm / (||g|| + 1e-6) when ||g|| > max_norm -> Adam, no weight decay; reference
