@@ -35,6 +35,7 @@ _SIGS = {
     "csm_gemm_bf16_dgrad_wgrad": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _f, _p], _i),
     "csm_gemm_bf16_two_wgrad": ([_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "csm_set_gemm_variant": ([_i], _i),
+    "csm_set_gemm256_persistent": ([_i], _i),
     "csm_rmsnorm_fwd": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
     "csm_rmsnorm_bwd_blocks": ([], _i),
     "csm_rmsnorm_bwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _p], _i),
@@ -86,6 +87,8 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.restype = _res
 
 EXPORTS = tuple(_SIGS)
+if os.environ.get("CSM_GEMM256_PERSISTENT") == "0":     # kernel A/B only (tools/probes)
+    lib.csm_set_gemm256_persistent(0)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -23,6 +23,12 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// sigmoid / SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (div_scale, rcp, 4 fma, div_fmas,
+// div_fixup: 11 instructions).  They sit in GEMM epilogues where a lane evaluates 64-128 of them per tile and no other
+// workgroup on the CU overlaps the epilogue; every SwiGLU site (GEMM epilogues, stand-alone kernels, decode) uses these two.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * fast_sigmoid(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

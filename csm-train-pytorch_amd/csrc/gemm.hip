@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
     e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N; e.p0 = g.epi_p0; e.p1 = g.epi_p1;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
-    epi_block<OutT, 4>(e, vec_ok, m0 + wm0, n0 + wn0, lane, acc);
+    (void)epi_block<OutT, 4>(e, vec_ok, m0 + wm0, n0 + wn0, lane, acc);
 }
 
 int g_gemm_variant = 2;   // 0 register staging, 1 LDS-DMA 128x128, 2 auto (256x256 where it fills the chip), 3 force 256x256
@@ -161,6 +161,10 @@ static bool prefer_256(int M, int N, int K, int batch) {
 
 // tuning / A-B switch (tools/gemm_bench.py, tests): 0 = 128x128 kernel with register staging, 1 = 128x128 kernel with
 // LDS-DMA staging, 2 = auto (default: the 256x256 kernel where its tiles fill the chip), 3 = force the 256x256 kernel
+extern int g_persistent;
+// A/B switch: 1 (default) = the 256x256 kernel runs one persistent workgroup per CU over its tile list, 0 = one tile per workgroup
+extern "C" int csm_set_gemm256_persistent(int v) { g_persistent = v ? 1 : 0; return 0; }
+
 extern "C" int csm_set_gemm_variant(int v) {
     CSM_REQUIRE(v >= 0 && v <= 3, "csm_set_gemm_variant: %d is not one of 0..3", v);
     g_gemm_variant = v;

@@ -11,6 +11,8 @@
 // for the previous tile's stores) and were removed; they are in the history.
 #include "gemm_common.h"
 
+int g_persistent = 1;     // csm_set_gemm256_persistent (gemm.hip)
+
 namespace {
 
 constexpr int HALF = 16384;            // bytes per half-tile
@@ -76,13 +78,21 @@ constexpr bool NO_PRIO = CSM_ABLATE & 64;    // no s_setprio around the MFMA gro
 constexpr bool EARLY_B = CSM_ABLATE & 32;    // flip the layout's default for the B half-tile issue phases (see the kernel)
 constexpr bool EARLY_A1 = CSM_ABLATE & 16;   // flip: A1 of the next tile in ph1 instead of with A0 in ph4
 
+#define WAIT_VM_DYN(n) do { switch (n) { case 63: WAIT_VM(63); break; case 56: WAIT_VM(56); break; case 52: WAIT_VM(52); break; \
+    case 40: WAIT_VM(40); break; case 36: WAIT_VM(36); break; case 24: WAIT_VM(24); break; case 20: WAIT_VM(20); break;       \
+    default: WAIT_VM(4); break; } } while (0)
+
+// ``id`` = first tile of this workgroup, ``stride`` = tiles between its consecutive tiles (the grid size of a persistent
+// launch; anything >= the tile count for one tile per workgroup).  A workgroup that has a next tile requests that tile's
+// first two K-tiles BEFORE it stores the finished one: the loads enter the memory system ahead of the 128 KiB of stores
+// every CU emits at the same moment (in a fresh workgroup they queue behind the previous round's stores), the store drain
+// overlaps the next main loop's first K-tiles, and no workgroup is torn down and launched between rounds.  Loads and
+// stores share one in-order counter, so the waits for those early loads are counted PAST the epilogue's memory
+// operations (``pend`` = a lower bound of their number, known for full tiles on the 16-byte epilogue paths; 0 otherwise,
+// which degrades to waiting for the stores as well).
 template <int TA, int TB, typename OutT>
-__device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const int bz, char* smem) {
+__device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const int stride, const int bz, char* smem) {
     const int nwg = g.tiles_m * g.tiles_n;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    }
     // m-tiles per raster group (the tiles an XCD works on at one time are GROUP_M m-tiles x 32 / GROUP_M n-tiles).
     // tools/probes/group_m_probe.sh: 8 and 16 lose 1-4 %; 2 wins 4 % on the bare N = 16384 GEMM but nothing in the real
     // step (tools/probes/ab_group_m_step.sh, where that GEMM carries the SwiGLU epilogue).  CSM_GROUP_M pins it for the probes.
@@ -90,13 +100,20 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
 #define CSM_GROUP_M 4
 #endif
     constexpr int GROUP_M = CSM_GROUP_M;
-    const int per_group = GROUP_M * g.tiles_n;
-    const int grp = id / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(g.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (id % per_group) % gsz;
-    const int tn = (id % per_group) / gsz;
-    const int m0 = tm * 256, n0 = tn * 256;
+    auto coords = [&](int t_id, int& m0_, int& n0_) {
+        {
+            const int q = nwg >> 3, r = nwg & 7, xcd = t_id & 7, within = t_id >> 3;
+            t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+        }
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = t_id / per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = min(g.tiles_m - first_m, GROUP_M);
+        m0_ = (first_m + (t_id % per_group) % gsz) * 256;
+        n0_ = ((t_id % per_group) / gsz) * 256;
+    };
+    int m0, n0;
+    coords(id, m0, n0);
 
     const bf16_t* A = g.A + (size_t)bz * g.sA;
     const bf16_t* B = g.B + (size_t)bz * g.sB;
@@ -106,10 +123,6 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     const int a_half = wr, b_half = wc >> 1, b_off = (wc & 1) * 64;
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // Issue order of the LDS-DMA half-tiles, measured per operand layout (tools/probes/ablate_gemm.sh, 5..9-round medians
     // on the train-step shapes; bits 16 / 32 of CSM_ABLATE flip the two choices):
@@ -127,11 +140,25 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     auto issueA = [&](int h, int tile, int b) { if (ABL_G && tile >= 2) return; issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slotA(b, h)); };
     auto issueB = [&](int h, int tile, int b3) { if (ABL_G && tile >= 2) return; issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slotB(b3, h)); };
     constexpr int NRA = (TA == 0) ? 4 : 8;     // LDS read instructions per prefetched A pair
-
-    issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
+    // the first two K-tiles of the output tile at (m0, n0): 8 + 8 (or 6) DMA instructions per wave
+    auto prologue = [&]() {
+        issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
+        if (nt > 1) {
+            issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1);
+            if (EARLY) issueA(1, 1, 1);
+        }
+    };
+    prologue();
+    int pend = 0;                               // memory operations of the previous tile's epilogue issued after the prologue
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 has landed (K-tile 1's 8 / 6 instructions and ``pend`` younger operations may still be in flight)
     if (nt > 1) {
-        issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1);
-        if (EARLY) { issueA(1, 1, 1); WAIT_VM(8); } else { WAIT_VM(6); }
+        if (pend > 0 && EARLY) { const int w = min(63, 8 + pend); WAIT_VM_DYN(w); }
+        else if (EARLY) { WAIT_VM(8); } else { if (pend > 0) { WAIT_VM(0); } else { WAIT_VM(6); } }
     } else { WAIT_VM(0); }
     BARRIER();
 
@@ -173,7 +200,8 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 4)
         WAIT_LGKM(0);                                           // pair-3 reads done: the A slots of this buffer are dead
-        if (t + 2 < nt) { WAIT_VM(4); } else { WAIT_VM(0); }    // tile t+1 has landed
+        // tile t+1 has landed (for t = 0 of a later tile of this workgroup, counted past the previous tile's stores)
+        if (t + 2 < nt) { if (t == 0 && pend > 0) { const int w = min(63, 4 + pend); WAIT_VM_DYN(w); } else { WAIT_VM(4); } } else { WAIT_VM(0); }
         if (!ABL_B) BARRIER();
         // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
         if (t + 2 < nt) { issueA(0, t + 2, b); if (EARLY) issueA(1, t + 2, b); }
@@ -187,25 +215,37 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
 
     if (g.kx) k_extend<8>(g.xA, g.xB, g.kx, g.M, g.N, m0 + wr * 128, n0 + wc * 64, lane, acc);
 
+    // next tile of this workgroup: its first K-tiles are requested before this tile's results are stored (every LDS read of
+    // this tile is behind the last K-tile's barrier, so the slots are free)
+    const int em0 = m0, en0 = n0;
+    id += stride;
+    const bool more = id < nwg;
+    if (more) { coords(id, m0, n0); prologue(); }
+
     Epi e;
     e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;
     e.R = g.R ? g.R + (size_t)bz * g.sR : nullptr;
     e.ldc = g.ldc; e.ldr = g.ldr; e.alpha = g.alpha; e.mode = g.epi_mode; e.aux_in = g.aux_in; e.aux_out = g.aux_out;
     e.ld_aux = g.ld_aux; e.M = g.M; e.N = g.N; e.p0 = g.epi_p0; e.p1 = g.epi_p1;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!e.R || (g.ldr & 3) == 0);
-    if constexpr (sizeof(OutT) == 2) {
-        if (e.mode == EPI_SWIGLU_BWD) {
-            epi_swiglu_bwd_block<8, 4>(e, m0 + wr * 128, n0 + wc * 64, lane, acc);
-            return;
-        }
+    const bool full = em0 + 256 <= g.M && en0 + 256 <= g.N;      // no lane of this tile skips a memory operation
+    bool swb = false;
+    if constexpr (sizeof(OutT) == 2) swb = e.mode == EPI_SWIGLU_BWD;
+    if (swb) {
+        if constexpr (sizeof(OutT) == 2) epi_swiglu_bwd_block<8, 4>(e, em0 + wr * 128, en0 + wc * 64, lane, acc);
+        pend = full ? 64 : 0;
+    } else {
+        pend = epi_block<OutT, 8>(e, vec_ok, em0 + wr * 128, en0 + wc * 64, lane, acc);
+        if (!full) pend = 0;
     }
-    epi_block<OutT, 8>(e, vec_ok, m0 + wr * 128, n0 + wc * 64, lane, acc);
+    if (!more) break;
+  }
 }
 
 template <int TA, int TB, typename OutT>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(Gemm256Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm256_body<TA, TB, OutT>(g, blockIdx.x, blockIdx.z, smem);
+    gemm256_body<TA, TB, OutT>(g, blockIdx.x, gridDim.x, blockIdx.z, smem);
 }
 
 // Two independent GEMMs in ONE launch: the dgrad (nn) and the wgrad (tn) of the same Linear layer, which share dY and
@@ -234,14 +274,16 @@ __global__ __launch_bounds__(512, 2) void gemm256pair_kernel(Gemm256Pair p) {
         const int rest = pos - full * per, left_a = p.na - full * p.ra;
         if (rest < left_a) { kind = 0; j = full * p.ra + rest; } else { kind = 1; j = full * p.rb + (rest - left_a); }
     }
-    if (kind == 0) gemm256_body<0, 1, bf16_t>(p.a, j, 0, smem);
-    else gemm256_body<1, 1, bf16_t>(p.b, j, 0, smem);
+    if (kind == 0) gemm256_body<0, 1, bf16_t>(p.a, j, 1 << 30, 0, smem);
+    else gemm256_body<1, 1, bf16_t>(p.b, j, 1 << 30, 0, smem);
 }
 
 
 template <int TA, int TB>
 int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) {
-    dim3 grid(g.tiles_m * g.tiles_n, 1, batch), block(512);
+    // persistent: at most one workgroup per CU, each walking tiles id, id + 256, ... (csm_set_gemm256_persistent(0): one tile each)
+    const int tiles = g.tiles_m * g.tiles_n;
+    dim3 grid(g_persistent && tiles > 256 ? 256 : tiles, 1, batch), block(512);
     const size_t lds = 10 * HALF;   // 160 KiB: the whole LDS of a CU
     static bool done[2] = {false, false};
     if (out_f32) {
@@ -265,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void gemm256two_tn_kernel(Gemm256Two p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int id = blockIdx.x;
     // longest first is moot (same K); keep each problem's tiles contiguous so that an XCD's L2 sees one operand set at a time
-    if (id < p.na) gemm256_body<1, 1, bf16_t>(p.a, id, 0, smem);
-    else gemm256_body<1, 1, bf16_t>(p.b, id - p.na, 0, smem);
+    if (id < p.na) gemm256_body<1, 1, bf16_t>(p.a, id, 1 << 30, 0, smem);
+    else gemm256_body<1, 1, bf16_t>(p.b, id - p.na, 1 << 30, 0, smem);
 }
 
 }  // namespace

@@ -210,7 +210,7 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float gt = g[2 * i], up = g[2 * i + 1];
-                const float sg = 1.f / (1.f + __expf(-gt));
+                const float sg = fast_sigmoid(gt);
                 o[2 * i] = v[i] * up * sg * (1.f + gt * (1.f - sg));
                 o[2 * i + 1] = v[i] * gt * sg;
             }
@@ -229,8 +229,8 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
             uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
             *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;
             if (e.mode == EPI_SWIGLU_FWD) {
-                const float a0 = v[0] / (1.f + __expf(-v[0])) * v[1];
-                const float a1 = v[2] / (1.f + __expf(-v[2])) * v[3];
+                const float a0 = silu(v[0]) * v[1];
+                const float a1 = silu(v[2]) * v[3];
                 *reinterpret_cast<uint32_t*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = pack2bf(a0, a1);
             }
         } else {
@@ -281,7 +281,7 @@ __device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int n
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = acc[i + ii][j][k] * e.alpha, gt = gv[2 * k], up = gv[2 * k + 1];
-                    const float sg = 1.f / (1.f + __expf(-gt));
+                    const float sg = fast_sigmoid(gt);
                     o[2 * k] = v * up * sg * (1.f + gt * (1.f - sg));
                     o[2 * k + 1] = v * gt * sg;
                 }
@@ -330,7 +330,7 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
     if (e.mode == EPI_SWIGLU_FWD) {   // v = g0,u0,g1,u1,g2,u2,g3,u3 (gate / up interleaved along N): four activations, one 8-byte store
         float a[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = v[2 * k] / (1.f + __expf(-v[2 * k])) * v[2 * k + 1];
+        for (int k = 0; k < 4; ++k) a[k] = silu(v[2 * k]) * v[2 * k + 1];
         uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
         *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
     }
@@ -342,8 +342,10 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
 // per-pair form does, each of the 2 NI reads costs a full memory round trip before its store can go (R may alias C, so
 // the compiler cannot hoist them itself): 16 serial round trips per wave in the 256x256 kernel, whose epilogue no other
 // workgroup on the CU overlaps.
+// Returns a lower bound of the vector-memory operations every wave issues when no lane is out of range (the persistent
+// 256x256 kernel counts its waits past them); 0 = unknown.
 template <typename OutT, int NI>
-__device__ __forceinline__ void epi_block(const Epi& e, bool vec_ok, int mb, int nb, int lane, const f32x4 (&acc)[NI][4]) {
+__device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int nb, int lane, const f32x4 (&acc)[NI][4]) {
     bool fast = false;
     if constexpr (sizeof(OutT) == 2)
         fast = vec_ok && (e.mode == EPI_NONE || (e.mode == EPI_ROPE && (e.p0 & 63) == 0 && (e.p1 & 7) == 0) ||
@@ -357,7 +359,7 @@ __device__ __forceinline__ void epi_block(const Epi& e, bool vec_ok, int mb, int
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) epi_store_pair<OutT>(e, vec_ok, m, nb + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
         }
-        return;
+        return 0;
     }
     if constexpr (sizeof(OutT) == 2) {
         const int g = lane >> 4;
@@ -414,7 +416,7 @@ __device__ __forceinline__ void epi_block(const Epi& e, bool vec_ok, int mb, int
                     if (m < e.M) *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + n) = pack8(v);
                 }
             }
-            return;
+            return 6 * NI;        // 4 NI table loads + 2 NI stores
         }
         // ---- everything else: all residual rows of the block first
         U4 rr[NI][2];
@@ -444,14 +446,16 @@ __device__ __forceinline__ void epi_block(const Epi& e, bool vec_ok, int mb, int
                     if (e.mode == EPI_SWIGLU_FWD) {
                         float a[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) a[k] = v[2 * k] / (1.f + __expf(-v[2 * k])) * v[2 * k + 1];
+                        for (int k = 0; k < 4; ++k) a[k] = silu(v[2 * k]) * v[2 * k + 1];
                         uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
                         *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
                     }
                 }
             }
         }
+        return 2 * NI * (1 + (e.R ? 1 : 0) + (e.mode == EPI_SWIGLU_FWD ? 1 : 0));
     }
+    return 0;
 }
 
 // K-extension: after the main loop, kx / 32 more MFMA k-steps whose operands come straight from global memory - xA [M][kx]

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
             float v = wave_sum(acc[0][b]);
             if constexpr (SWIGLU) {
                 const float g = bf2f(f2bf(v)), u = bf2f(f2bf(wave_sum(acc[1][b])));
-                v = g / (1.f + __expf(-g)) * u;
+                v = silu(g) * u;
             }
             if (lane == 0) {
                 if (R) v += bf2f(R[(size_t)b * ldy + n]);

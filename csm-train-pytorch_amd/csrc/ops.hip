@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
         float g[8];
         unpack8(*reinterpret_cast<const U4*>(gu + (size_t)row * 2 * F + c * 8), g);
         uint2 o;
-        o.x = pack2bf(g[0] / (1.f + __expf(-g[0])) * g[1], g[2] / (1.f + __expf(-g[2])) * g[3]);
-        o.y = pack2bf(g[4] / (1.f + __expf(-g[4])) * g[5], g[6] / (1.f + __expf(-g[6])) * g[7]);
+        o.x = pack2bf(silu(g[0]) * g[1], silu(g[2]) * g[3]);
+        o.y = pack2bf(silu(g[4]) * g[5], silu(g[6]) * g[7]);
         *reinterpret_cast<uint2*>(out + (size_t)row * F + c * 4) = o;
     }
 }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float gt = g[2 * i], up = g[2 * i + 1];
-            const float sg = 1.f / (1.f + __expf(-gt));
+            const float sg = fast_sigmoid(gt);
             o[2 * i] = d[i] * up * sg * (1.f + gt * (1.f - sg));
             o[2 * i + 1] = d[i] * gt * sg;
         }

@@ -85,6 +85,9 @@ int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW1, int N1, 
 /* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = the 256x256 pipelined kernel
  * where its tiles fill the chip, else 128x128 (default); 3 force the 256x256 kernel */
 int csm_set_gemm_variant(int v);
+/* tuning switch: 1 (default) the 256x256 kernel runs one persistent workgroup per CU over its tile list (the next tile's first
+ * loads are requested before the finished tile is stored); 0 one tile per workgroup */
+int csm_set_gemm256_persistent(int v);
 
 /* ---- K2: torchtune RMSNorm (sa_norm / mlp_norm / norm; eps=1e-5 at model.py:22,39) -------------------------- */
 int csm_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int M, int D, float eps, csm_stream_t stream);
