@@ -56,6 +56,55 @@ __device__ __forceinline__ void issue_half(const bf16_t* __restrict__ P, int ld,
     }
 }
 
+// The same half-tile with the address split into a wave-uniform base (scalar registers, advanced per K-tile by scalar adds)
+// and a per-lane byte offset computed ONCE per output tile: the K loop then spends no vector instructions on addresses
+// (recomputing row * ld + column per piece cost ~130 VALU instructions per K-tile and wave - 64-bit multiplies among them -
+// on the issue port the MFMAs need).
+struct DmaSrc {
+    const char* base[2];      // K-tile 0 of half h (uniform)
+    unsigned off[2][2];       // per-lane byte offset of piece i of half h
+    long long step;           // bytes per K-tile
+};
+template <int T>
+__device__ __forceinline__ void dma_prepare(const bf16_t* __restrict__ P, int ld, int rows, int row0, DmaSrc& d) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    d.step = T == 0 ? 128 : (long long)ld * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (T == 0) {
+            const int ub = min(row0 + h * 128, rows - 1);                       // uniform first row (clamped like the lanes' rows)
+            d.base[h] = reinterpret_cast<const char*>(P + (size_t)ub * ld);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = wave * 2 + i;
+                const int r = 8 * j + (lane >> 3);
+                const int c = (lane & 7) ^ (r & 7);
+                const int rel = min(r, rows - 1 - ub);                          // row ub + rel = min(row0 + 128 h + r, rows - 1)
+                d.off[h][i] = (unsigned)(rel * ld + c * 8) * 2u;
+            }
+        } else {
+            const int ub = min(row0 + h * 128, rows - 8);
+            d.base[h] = reinterpret_cast<const char*>(P + ub);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = wave * 2 + i;
+                const int kr = 4 * j + (lane >> 4);
+                const int u = lane & 15;
+                const int sl = (u >> 1) ^ ks_swz(kr);
+                const int gc = min(row0 + h * 128 + sl * 16 + (u & 1) * 8, rows - 8);
+                d.off[h][i] = (unsigned)(kr * ld + (gc - ub)) * 2u;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void issue_half_pre(const DmaSrc& d, int h, const char* b /* d.base[h] + K-tile * d.step, uniform */, char* lds) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + d.off[h][i]),
+                                         (__attribute__((address_space(3))) void*)(lds + (wave * 2 + i) * 1024), 16, 0, 0);
+}
+
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
 
@@ -137,15 +186,22 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     // LDS map (160 KiB): A double-buffered [2][2 halves] at 0..64 KiB, B TRIPLE-buffered [3][2 halves] at 64..160 KiB
     auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
     auto slotB = [&](int b3, int h) { return smem + 4 * HALF + b3 * (2 * HALF) + h * HALF; };
-    auto issueA = [&](int h, int tile, int b) { if (ABL_G && tile >= 2) return; issue_half<TA>(A, g.lda, g.M, m0 + h * 128, tile * 64, slotA(b, h)); };
-    auto issueB = [&](int h, int tile, int b3) { if (ABL_G && tile >= 2) return; issue_half<TB>(B, g.ldb, g.N, n0 + h * 128, tile * 64, slotB(b3, h)); };
+    DmaSrc srcA, srcB;
+    const char *pa[2], *pb[2];                  // K-tile t + 2 of each half: running pointers, advanced by scalar adds (no multiplies in the loop)
+    // ``rel``: K-tile relative to the running pointers' tile (0 = tile t + 2 inside the loop, -1 = tile t + 1)
+    auto issueA = [&](int h, int rel, int tile, int b) { if (ABL_G && tile >= 2) return; issue_half_pre(srcA, h, pa[h] + rel * srcA.step, slotA(b, h)); };
+    auto issueB = [&](int h, int rel, int tile, int b3) { if (ABL_G && tile >= 2) return; issue_half_pre(srcB, h, pb[h] + rel * srcB.step, slotB(b3, h)); };
     constexpr int NRA = (TA == 0) ? 4 : 8;     // LDS read instructions per prefetched A pair
     // the first two K-tiles of the output tile at (m0, n0): 8 + 8 (or 6) DMA instructions per wave
     auto prologue = [&]() {
-        issueA(0, 0, 0); issueA(1, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0);
+        dma_prepare<TA>(A, g.lda, g.M, m0, srcA);
+        dma_prepare<TB>(B, g.ldb, g.N, n0, srcB);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { pa[h] = srcA.base[h] + 2 * srcA.step; pb[h] = srcB.base[h] + 2 * srcB.step; }
+        issueA(0, -2, 0, 0); issueA(1, -2, 0, 0); issueB(0, -2, 0, 0); issueB(1, -2, 0, 0);
         if (nt > 1) {
-            issueB(0, 1, 1); issueB(1, 1, 1); issueA(0, 1, 1);
-            if (EARLY) issueA(1, 1, 1);
+            issueB(0, -1, 1, 1); issueB(1, -1, 1, 1); issueA(0, -1, 1, 1);
+            if (EARLY) issueA(1, -1, 1, 1);
         }
     };
     prologue();
@@ -182,20 +238,20 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         const char* la = slotA(b, a_half);
         const char* lb = slotB(b3, b_half);
         // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
-        if (!EARLY && t + 1 < nt) issueA(1, t + 1, b ^ 1);
-        if (EARLYB && t + 2 < nt) issueB(0, t + 2, b3n);
+        if (!EARLY && t + 1 < nt) issueA(1, -1, t + 1, b ^ 1);
+        if (EARLYB && t + 2 < nt) issueB(0, 0, t + 2, b3n);
         if (!ABL_L) { fb.load(lb, b_off, lane);
         fa1.load(la, 32, lane); }
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 0)
         // ---- ph2: pair 1 (set 1)   | prefetch pair 2 -> set 0
-        if (t + 2 < nt) issueB(EARLYB ? 1 : 0, t + 2, b3n);
+        if (t + 2 < nt) issueB(EARLYB ? 1 : 0, 0, t + 2, b3n);
         if (!ABL_L) fa0.load(la, 64, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 2)
         // (no barrier: the B slots were released by ph1's barrier, nothing new has to be visible yet)
         // ---- ph3: pair 2 (set 0)   | prefetch pair 3 -> set 1
-        if (!EARLYB && t + 2 < nt) issueB(1, t + 2, b3n);
+        if (!EARLYB && t + 2 < nt) issueB(1, 0, t + 2, b3n);
         if (!ABL_L) fa1.load(la, 96, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 4)
@@ -204,12 +260,14 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         if (t + 2 < nt) { if (t == 0 && pend > 0) { const int w = min(63, 4 + pend); WAIT_VM_DYN(w); } else { WAIT_VM(4); } } else { WAIT_VM(0); }
         if (!ABL_B) BARRIER();
         // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
-        if (t + 2 < nt) { issueA(0, t + 2, b); if (EARLY) issueA(1, t + 2, b); }
+        if (t + 2 < nt) { issueA(0, 0, t + 2, b); if (EARLY) issueA(1, 0, t + 2, b); }
         if (!ABL_L && t + 1 < nt) fa0.load(slotA(b ^ 1, a_half), 0, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 6)
         // (no barrier: ph1(t+1) only touches slots ph3's barrier has already released / published)
         b3 = b3 == 2 ? 0 : b3 + 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { pa[h] += srcA.step; pb[h] += srcB.step; }
     }
 #undef MFMA_PAIR
 
