@@ -77,14 +77,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), fa.get(i, ks), acc[i][j], 0, 0, 0);
     };
     if constexpr (GLDS) {
-        stage_glds<TA>(A, g.lda, g.M, m0, 0, ldsA(0));
-        stage_glds<TB>(B, g.ldb, g.N, n0, 0, ldsB(0));
+        GldsSrc sa, sb;
+        glds_prepare<TA>(A, g.lda, g.M, m0, sa);
+        glds_prepare<TB>(B, g.ldb, g.N, n0, sb);
+        const char *pa = sa.base, *pb = sb.base;          // running pointers: K-tile t + 1 inside the loop
+        stage_glds_pre(sa, pa, ldsA(0));
+        stage_glds_pre(sb, pb, ldsB(0));
         __syncthreads();   // waits vmcnt(0) for the LDS-DMA, then the barrier
         for (int t = 0; t < nt; ++t) {
             const int cur = t & 1;
+            pa += sa.step; pb += sb.step;
             if (t + 1 < nt) {
-                stage_glds<TA>(A, g.lda, g.M, m0, (t + 1) * BK, ldsA(cur ^ 1));
-                stage_glds<TB>(B, g.ldb, g.N, n0, (t + 1) * BK, ldsB(cur ^ 1));
+                stage_glds_pre(sa, pa, ldsA(cur ^ 1));
+                stage_glds_pre(sb, pb, ldsB(cur ^ 1));
             }
             compute(cur);
             __syncthreads();

@@ -93,6 +93,44 @@ __device__ __forceinline__ void stage_glds(const bf16_t* __restrict__ P, int ld,
     }
 }
 
+// The same tile with the source address split into a wave-uniform base (scalar, advanced per K-tile by scalar adds) and
+// per-lane byte offsets computed ONCE per output tile: the K loop spends one vector add per piece on addresses instead of
+// a clamped 64-bit row * ld + column per piece (~16 vector instructions each, on the issue port the MFMAs need).
+struct GldsSrc {
+    const char* base;      // K-tile 0 (uniform)
+    unsigned off[4];       // per-lane byte offset of piece i
+    long long step;        // bytes per K-tile
+};
+template <int T>
+__device__ __forceinline__ void glds_prepare(const bf16_t* __restrict__ P, int ld, int rows, int row0, GldsSrc& d) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    d.step = T == 0 ? 2 * BK : (long long)ld * 2 * BK;
+    const int ub = T == 0 ? min(row0, rows - 1) : min(row0, rows - 8);      // uniform first row / column, clamped like the lanes'
+    d.base = reinterpret_cast<const char*>(T == 0 ? P + (size_t)ub * ld : P + ub);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i;
+        if (T == 0) {
+            const int r = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            d.off[i] = (unsigned)(min(r, rows - 1 - ub) * ld + c * 8) * 2u;
+        } else {
+            const int kr = 4 * j + (lane >> 4);
+            const int u = lane & 15;
+            const int sl = (u >> 1) ^ ks_swz(kr);
+            const int gc = min(row0 + sl * 16 + (u & 1) * 8, rows - 8);
+            d.off[i] = (unsigned)(kr * ld + (gc - ub)) * 2u;
+        }
+    }
+}
+__device__ __forceinline__ void stage_glds_pre(const GldsSrc& d, const char* b /* d.base + K-tile * d.step */, char* lds) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + d.off[i]),
+                                         (__attribute__((address_space(3))) void*)(lds + (wave * 4 + i) * 1024), 16, 0, 0);
+}
+
 // ---- fragments ---------------------------------------------------------------------------------------------
 // Fragment of 16 tile-rows starting at r0 for k-step ks (32 deep): lane holds row (lane&15), k = 8*(lane>>4)+j.
 //
