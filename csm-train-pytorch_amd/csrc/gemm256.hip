@@ -179,9 +179,11 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     //            more phase of latency slack.  nn: 4-6 % faster; with EARLYB also nt (2-5 %) and tn (7 %).
     //   EARLYB - the B halves of tile t+2 in ph1/ph2 instead of ph2/ph3.  Helps nt and tn, costs nn 5 % -> off for nn.
     // Putting all four in one phase (ph4: A(t+2), B(t+3)) was 4-12 % slower: the DMA wants to be spread out.
-    constexpr bool NN = (TA == 0 && TB == 1);
-    constexpr bool EARLY = !EARLY_A1;
-    constexpr bool EARLYB = EARLY_B ? NN : !NN;
+    // Re-measured after the DMA addresses left the vector pipe (round 2, tools/probes/ablate_gemm2.sh): tn is now 2-3 % faster
+    // with neither (A1 of the next tile in ph1, B halves in ph2 / ph3); nt is indifferent; nn unchanged.
+    constexpr bool NN = (TA == 0 && TB == 1), TN = (TA == 1 && TB == 1);
+    constexpr bool EARLY = EARLY_A1 ? TN : !TN;
+    constexpr bool EARLYB = EARLY_B ? (NN || TN) : !(NN || TN);
     const int nt = g.K / 64;
     // LDS map (160 KiB): A double-buffered [2][2 halves] at 0..64 KiB, B TRIPLE-buffered [3][2 halves] at 64..160 KiB
     auto slotA = [&](int b, int h) { return smem + b * (2 * HALF) + h * HALF; };
