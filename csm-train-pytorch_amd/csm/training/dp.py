@@ -114,6 +114,12 @@ class GradSync:
         extra = [model.lora.grad_arena] if model.lora is not None else []
         gs = cls(model.grad_arena, merged, group, extra)
         gs.sparse = sparse
+        if gs.world_size > 1 and model.grad_arena.is_cuda and "CSM_GEMM256_PERSISTENT" not in os.environ:
+            # The collectives' workgroups hold a few CUs while the backward runs.  A persistent GEMM launches one workgroup per CU
+            # with a fixed tile list each, so the workgroups that find their CU taken would run their whole list late; one tile
+            # per workgroup lets the dispatcher pack the remaining CUs instead.  (Single-GPU runs keep the persistent form.)
+            from ..hip import lib
+            lib.csm_set_gemm256_persistent(0)
         model.engine.grad_hook = gs.on_ready
         return gs
 
