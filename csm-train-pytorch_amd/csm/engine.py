@@ -328,6 +328,8 @@ class Engine:
         self._validate_batch(tokens, masks, targets, ign)
         tg = targets.to(device=dev, dtype=torch.int64)
 
+        if m.lora is not None and LORA_FUSE:
+            m.lora.refresh()
         h0 = torch.empty(M, d, dtype=BF16, device=dev)
         ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, V)
         hidden = self.backbone.forward(h0, B, S, save)

@@ -32,6 +32,7 @@ _SIGS = {
     "csm_gemm_bf16_ex": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _ll, _ll, _ll, _ll, _i, _p, _p, _i, _p], _i),
     "csm_gemm_bf16_rope": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p], _i),
     "csm_gemm_bf16_kext": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p], _i),
+    "csm_skinny_nt_bf16": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "csm_gemm_bf16_dgrad_wgrad": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _f, _p], _i),
     "csm_gemm_bf16_two_wgrad": ([_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "csm_set_gemm_variant": ([_i], _i),

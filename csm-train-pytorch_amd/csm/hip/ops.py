@@ -105,6 +105,18 @@ def gemm_kext(A, B, C, xA, xB, R=None, transB=False, rope=None, swiglu_act=None,
     return C
 
 
+def skinny_nt(x, wt, out, alpha=1.0):
+    """out[M,N] = alpha * x[M,K] wt[N,K]^T for N in (32, 64): the bandwidth-shaped product of a LoRA group (falls back to the
+    GEMM for other widths)."""
+    pa, M, K, lda = _mat(x)
+    pb, N, Kb, ldb = _mat(wt)
+    assert K == Kb and out.shape == (M, N) and out.dtype == BF16 and out.stride(1) == 1
+    if N not in (32, 64) or K % 64:
+        return gemm(x, wt, out, None, False, False, alpha)
+    check(lib.csm_skinny_nt_bf16(pa, pb, out.data_ptr(), M, N, K, lda, ldb, out.stride(0), float(alpha), _stream()), "csm_skinny_nt_bf16")
+    return out
+
+
 def linear_fwd(x, w, out, residual=None, alpha=1.0):
     """out[M,N] = x[M,K] w[N,K]^T (+ residual)."""
     return gemm(x, w, out, residual, False, False, alpha)

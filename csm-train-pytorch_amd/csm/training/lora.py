@@ -129,6 +129,7 @@ class LoRAGroup:
         self.kx = At.shape[1]
         self.adapters: Dict[str, LoRAAdapter] = OrderedDict()
         self.mask = None           # 0/1 [N, KX] over Bx when entries outside the adapters' blocks could receive a gradient
+        self.AtT = self.BxT = None  # [KX, in] / [KX, N] copies for the bandwidth-shaped skinny products (LoRAState.refresh)
 
     def fusable(self) -> bool:
         """One operand pair for the whole group: no bias, and no dropout mask to draw in this pass."""
@@ -138,13 +139,19 @@ class LoRAGroup:
     def project(self, x):
         """tx = s x At  [M, KX]: the extension operand of the forward GEMM (kept for the backward)."""
         tx = torch.empty(x.shape[0], self.kx, dtype=BF16, device=x.device)
-        ops.gemm(x, self.At, tx, None, False, True, alpha=self.state.scaling)
+        if self.AtT is not None:
+            ops.skinny_nt(x, self.AtT, tx, alpha=self.state.scaling)
+        else:
+            ops.gemm(x, self.At, tx, None, False, True, alpha=self.state.scaling)
         return tx
 
     def backward(self, x, dy, tx):
         """Weight gradients of the group and the extension operand of the input-gradient GEMM: returns dts = s dy Bx."""
         dts = torch.empty(dy.shape[0], self.kx, dtype=BF16, device=dy.device)
-        ops.gemm(dy, self.Bx, dts, None, False, True, alpha=self.state.scaling)
+        if self.BxT is not None:
+            ops.skinny_nt(dy, self.BxT, dts, alpha=self.state.scaling)
+        else:
+            ops.gemm(dy, self.Bx, dts, None, False, True, alpha=self.state.scaling)
         skinny_wgrad(dy, tx, self.gBx)              # d/dBx = dy^T (s x At)
         if self.mask is not None:
             self.gBx.mul_(self.mask)
@@ -206,11 +213,27 @@ class LoRAState:
             off += n
             return w, gr
 
-        for prefix, i, gname, in_f, rows, present in plan:
-            kx = kx_of(len(present))
-            At, gAt = take(in_f * kx, (in_f, kx))
-            Bx, gBx = take(rows * kx, (rows, kx))
-            grp = LoRAGroup(self, f"{prefix}.layers.{i}.{gname}", At, Bx, gAt, gBx)
+        # the groups of one kind in one stack lie side by side ([layers, in, KX] and [layers, N, KX]): refresh() transposes
+        # a whole stack with one copy
+        stacks = OrderedDict()
+        for entry in plan:
+            stacks.setdefault((entry[0], entry[2]), []).append(entry)
+        self.stacks = []
+        built = {}
+        for (prefix, gname), entries in stacks.items():
+            _, _, _, in_f, rows, present = entries[0]
+            kx, L = kx_of(len(present)), len(entries)
+            At_all, gAt_all = take(L * in_f * kx, (L, in_f, kx))
+            Bx_all, gBx_all = take(L * rows * kx, (L, rows, kx))
+            grps = []
+            for li, (_, i, _, _, _, _) in enumerate(entries):
+                grp = LoRAGroup(self, f"{prefix}.layers.{i}.{gname}", At_all[li], Bx_all[li], gAt_all[li], gBx_all[li])
+                built[(prefix, i, gname)] = (grp, present, in_f, rows)
+                grps.append(grp)
+            self.stacks.append((At_all, Bx_all, grps))
+        for prefix, i, gname, in_f, rows, present in plan:          # adapters in plan order (layer-major), as named_tensors lists them
+            grp, _, _, _ = built[(prefix, i, gname)]
+            At, Bx, gAt, gBx, kx = grp.At, grp.Bx, grp.gAt, grp.gBx, grp.kx
             covered = torch.zeros(rows, kx, dtype=BF16, device=dev)
             for j, (mod, out_f, sl) in enumerate(present):
                 c0 = j * rp
@@ -227,6 +250,16 @@ class LoRAState:
             if bool((covered[:, :len(present) * rp] == 0).any()):
                 grp.mask = covered
             self.groups[(prefix, i, gname)] = grp
+
+    @torch.no_grad()
+    def refresh(self):
+        """[KX, in] / [KX, N] transposes of every group's matrices, one copy per stack and kind: what the bandwidth-shaped
+        skinny products (csm_skinny_nt_bf16) read.  Called at the start of every forward pass (the parameters may have
+        moved since the last one)."""
+        for At_all, Bx_all, grps in self.stacks:
+            AtT, BxT = At_all.transpose(1, 2).contiguous(), Bx_all.transpose(1, 2).contiguous()
+            for li, grp in enumerate(grps):
+                grp.AtT, grp.BxT = AtT[li], BxT[li]
 
     def get(self, prefix, layer, module):
         return self.adapters.get((prefix, layer, module))
