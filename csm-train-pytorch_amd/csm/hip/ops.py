@@ -111,7 +111,7 @@ def skinny_nt(x, wt, out, alpha=1.0):
     pa, M, K, lda = _mat(x)
     pb, N, Kb, ldb = _mat(wt)
     assert K == Kb and out.shape == (M, N) and out.dtype == BF16 and out.stride(1) == 1
-    if N not in (32, 64) or K % 64:
+    if N not in (32, 64) or K % 128:
         return gemm(x, wt, out, None, False, False, alpha)
     check(lib.csm_skinny_nt_bf16(pa, pb, out.data_ptr(), M, N, K, lda, ldb, out.stride(0), float(alpha), _stream()), "csm_skinny_nt_bf16")
     return out

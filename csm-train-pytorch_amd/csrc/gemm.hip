@@ -131,19 +131,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 // Skinny product out[M][N] = alpha * X[M][K] . Wt[N][K]^T for N = 32 or 64 (a LoRA group's ranks): a pure bandwidth problem -
 // X is read once (M K 2 bytes), Wt (N K 2 bytes, tens of KB) stays in L2 - that a 128x128 GEMM tile serves badly (M / 128
-// workgroups, each walking K serially, 3/4 of every MFMA wasted).  Here a workgroup owns 32 rows: wave w takes the 16 rows of
-// group (w & 1) and the K half (w >> 1); both operands are K-contiguous, so the MFMA fragments are plain 16-byte global
-// loads into registers (8 k-steps = 24-40 loads in flight per lane), no LDS until the two K halves are added at the end.
+// workgroups, each walking K serially, 3/4 of every MFMA wasted).  Here a workgroup owns 16 rows and its four waves a quarter
+// of K each (M / 16 x 4 waves = 16 waves per CU at M = 16k: the latency of a short read-once stream is hidden by the number
+// of waves, not by depth); both operands are K-contiguous, so the MFMA fragments are plain 16-byte global loads into
+// registers (8 k-steps = 24-40 loads in flight per lane), no LDS until the four partial sums are added at the end.
 template <int NT /* N / 16 */>
 __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, bf16_t* __restrict__ out,
                                                         int M, int K, int ldx, int ldw, int ldo, float alpha) {
-    __shared__ float red[2][NT][64][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = wave & 1, kh = wave >> 1;
-    const int m0 = blockIdx.x * 32 + rg * 16;
+    __shared__ float red[3][NT][64][4];
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 16;
     const int row = min(m0 + (lane & 15), M - 1);
     const int c = (lane >> 4) * 8;
-    const int kbeg = kh * (K >> 1), kend = kbeg + (K >> 1);
+    const int kbeg = kq * (K >> 2), kend = kbeg + (K >> 2);
     const bf16_t* xp = X + (size_t)row * ldx + c;
     const bf16_t* wp = Wt + (size_t)(lane & 15) * ldw + c;
     f32x4 acc[NT];
@@ -166,20 +166,20 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
                 for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][j], fx[u], acc[j], 0, 0, 0);
             }
     }
-    // lane holds out[m0 + (lane & 15)][16 j + 4 (lane >> 4) .. + 3]; add the two K halves through LDS
-    if (kh == 1) {
+    // lane holds out[m0 + (lane & 15)][16 j + 4 (lane >> 4) .. + 3]; add the four K quarters through LDS (fixed order)
+    if (kq > 0) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[rg][j][lane][r] = acc[j][r];
+            for (int r = 0; r < 4; ++r) red[kq - 1][j][lane][r] = acc[j][r];
     }
     __syncthreads();
-    if (kh == 0 && m0 + (lane & 15) < M) {
+    if (kq == 0 && m0 + (lane & 15) < M) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (acc[j][r] + red[rg][j][lane][r]) * alpha;
+            for (int r = 0; r < 4; ++r) v[r] = (((acc[j][r] + red[0][j][lane][r]) + red[1][j][lane][r]) + red[2][j][lane][r]) * alpha;
             uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
             *reinterpret_cast<uint2*>(out + (size_t)(m0 + (lane & 15)) * ldo + 16 * j + 4 * (lane >> 4)) = o;
         }
@@ -316,15 +316,15 @@ extern "C" int csm_gemm_bf16_kext(const void* A, const void* B, void* C, const v
                          stream, epilogue == 3 ? rope_cols : 0, epilogue == 3 ? head_dim : 0, xA, xB, kx);
 }
 
-// out[M][N] = alpha * X[M][K] . Wt[N][K]^T, N = 32 or 64, K a multiple of 64 - the skinny products of a LoRA group (reference
+// out[M][N] = alpha * X[M][K] . Wt[N][K]^T, N = 32 or 64, K a multiple of 128 - the skinny products of a LoRA group (reference
 // LoRALinear: x A^T and dy B, src/csm/mlx/components/lora.py:85-105), shaped for bandwidth instead of MFMA tiles.
 extern "C" int csm_skinny_nt_bf16(const void* X, const void* Wt, void* out, int M, int N, int K, int ldx, int ldw, int ldo, float alpha,
                                   hipStream_t stream) {
     CSM_REQUIRE(X && Wt && out && M > 0, "csm_skinny_nt_bf16: null operand");
-    CSM_REQUIRE((N == 32 || N == 64) && K >= 64 && K % 64 == 0, "csm_skinny_nt_bf16: N must be 32 or 64 and K a multiple of 64 (N=%d K=%d)", N, K);
+    CSM_REQUIRE((N == 32 || N == 64) && K >= 128 && K % 128 == 0, "csm_skinny_nt_bf16: N must be 32 or 64 and K a multiple of 128 (N=%d K=%d)", N, K);
     CSM_REQUIRE((ldx & 7) == 0 && (ldw & 7) == 0 && (ldo & 3) == 0 && ldx >= K && ldw >= K && ldo >= N, "csm_skinny_nt_bf16: bad leading dimensions");
     CSM_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Wt & 15) == 0 && ((uintptr_t)out & 7) == 0, "csm_skinny_nt_bf16: operands must be 16-byte aligned");
-    const dim3 grid((M + 31) / 32), block(256);
+    const dim3 grid((M + 15) / 16), block(256);
     if (N == 32) hipLaunchKernelGGL((skinny_nt_kernel<2>), grid, block, 0, stream, (const bf16_t*)X, (const bf16_t*)Wt, (bf16_t*)out, M, K, ldx, ldw, ldo, alpha);
     else hipLaunchKernelGGL((skinny_nt_kernel<4>), grid, block, 0, stream, (const bf16_t*)X, (const bf16_t*)Wt, (bf16_t*)out, M, K, ldx, ldw, ldo, alpha);
     CSM_CHECK_LAUNCH("csm_skinny_nt_bf16");

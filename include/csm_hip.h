@@ -66,7 +66,7 @@ int csm_gemm_bf16_rope(const void* A, const void* W, void* C, int M, int N, int 
 int csm_gemm_bf16_kext(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
                        int transA, int transB, const void* xA, const void* xB, int kx, int epilogue, const void* aux_in,
                        void* aux_out, int ld_aux, int rope_cols, int head_dim, csm_stream_t stream);
-/* out[M][N] = alpha * X[M][K] Wt[N][K]^T for N = 32 or 64 and K % 64 == 0: the skinny products of a LoRA group (x A^T and dy B of
+/* out[M][N] = alpha * X[M][K] Wt[N][K]^T for N = 32 or 64 and K % 128 == 0: the skinny products of a LoRA group (x A^T and dy B of
  * reference src/csm/mlx/components/lora.py:85-105 with the group's ranks side by side), read-once bandwidth kernel. */
 int csm_skinny_nt_bf16(const void* X, const void* Wt, void* out, int M, int N, int K, int ldx, int ldw, int ldo, float alpha,
                        csm_stream_t stream);

@@ -353,7 +353,7 @@ def test_gemm_k_extension(dev, M, N, K, kx, transB, epi):
         assert torch.equal(z, plain)
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 32, 2048), (4096, 64, 3072), (100, 32, 192), (33, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(16384, 32, 2048), (4096, 64, 3072), (100, 32, 384), (33, 64, 128), (50, 32, 192)])
 def test_skinny_nt(dev, M, N, K):
     """csm_skinny_nt_bf16: out = alpha x wt^T for a LoRA group's ranks, against fp32 (ragged M, K halves that are not a
     multiple of the unrolled step, both widths)."""
@@ -364,7 +364,7 @@ def test_skinny_nt(dev, M, N, K):
     out = torch.empty(M, N, dtype=BF, device=dev)
     ops.skinny_nt(x.to(dev), wt.to(dev), out, alpha=2.0)
     close("skinny nt", out, 2.0 * (x.float() @ wt.float().t()), 1e-2)
-    xs = x.to(dev)[:, :K // 2 // 64 * 64] if K >= 256 else None          # a strided view as input (ld > K)
+    xs = x.to(dev)[:, :K // 2 // 128 * 128] if K >= 256 else None        # a strided view as input (ld > K)
     if xs is not None:
         o2 = torch.empty(M, N, dtype=BF, device=dev)
         ops.skinny_nt(xs, wt.to(dev)[:, :xs.shape[1]], o2)
