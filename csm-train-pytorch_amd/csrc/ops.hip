@@ -463,6 +463,59 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     }
 }
 
+// The same with ONE WAVE per row and the row in registers (NC float4 per lane): one pass over the logits instead of three
+// block-wide ones with two barriers each, 16-byte loads, 8-byte stores.  Used when the row fits (V <= 256 NC) and the
+// leading dimensions allow the vector accesses.
+template <int NC>
+__global__ __launch_bounds__(256) void ce_wave_kernel(const float* __restrict__ logits, const long long* __restrict__ targets,
+                                                      float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, long long R, int V,
+                                                      int ldl, int ldd, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* x = logits + (size_t)row * ldl;
+    const long long t = targets[row];
+    if (t < 0) {
+        if (lane == 0) loss_rows[row] = 0.f;
+        if (dlogits)
+            for (int c = lane * 4; c < ldd; c += 256) *reinterpret_cast<uint2*>(dlogits + (size_t)row * ldd + c) = make_uint2(0u, 0u);
+        return;
+    }
+    float v[NC][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        float4 q = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (c < ldl) q = *reinterpret_cast<const float4*>(x + c);
+        v[i][0] = c + 0 < V ? q.x : -INFINITY; v[i][1] = c + 1 < V ? q.y : -INFINITY;
+        v[i][2] = c + 2 < V ? q.z : -INFINITY; v[i][3] = c + 3 < V ? q.w : -INFINITY;
+        mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += __expf(v[i][j] - mx);        // exp(-inf) = 0 for the masked columns
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    if (lane == 0) loss_rows[row] = lse - x[t];
+    if (dlogits) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < ldd) {
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = c + j < V ? (__expf(v[i][j] - lse) - (c + j == t ? 1.f : 0.f)) * gscale : 0.f;
+                uint2 o; o.x = pack2bf(g[0], g[1]); o.y = pack2bf(g[2], g[3]);
+                *reinterpret_cast<uint2*>(dlogits + (size_t)row * ldd + c) = o;
+            }
+        }
+    }
+}
+
 // deterministic single-block sum: out[0] = scale * sum(x[0..n))
 __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, long long n, float scale,
                                                           float* __restrict__ out) {
@@ -762,8 +815,17 @@ extern "C" int csm_ce_fwd_bwd(const float* logits, const long long* targets, flo
                               int V, int ldl, int ldd, float grad_scale, hipStream_t stream) {
     CSM_REQUIRE(logits && targets && loss_rows && R > 0 && R < (1ll << 31) && V > 0 && ldl >= V, "csm_ce_fwd_bwd: bad arguments");
     CSM_REQUIRE(!dlogits || ldd >= V, "csm_ce_fwd_bwd: ldd < V");
-    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, loss_rows, (bf16_t*)dlogits, V, ldl,
-                       ldd, grad_scale);
+    const int width = ldl > ldd && dlogits ? ldl : (dlogits ? ldd : ldl);          // columns a lane pattern must cover
+    const bool vec = (ldl & 3) == 0 && ((uintptr_t)logits & 15) == 0 && (!dlogits || ((ldd & 3) == 0 && ((uintptr_t)dlogits & 7) == 0 && ldd <= ldl + 0));
+    if (vec && width <= 256 * 12) {
+        const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+#define L(NC) hipLaunchKernelGGL((ce_wave_kernel<NC>), grid, block, 0, stream, logits, targets, loss_rows, (bf16_t*)dlogits, R, V, ldl, ldd, grad_scale)
+        if (width <= 256 * 4) L(4); else if (width <= 256 * 9) L(9); else L(12);
+#undef L
+    } else {
+        hipLaunchKernelGGL(ce_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, targets, loss_rows, (bf16_t*)dlogits, V, ldl,
+                           ldd, grad_scale);
+    }
     CSM_CHECK_LAUNCH("csm_ce_fwd_bwd");
     return 0;
 }
