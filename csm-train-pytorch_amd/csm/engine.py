@@ -175,7 +175,7 @@ class _Stack:
         table = self.m.rope_table(self.prefix)
         nb = ops.lib.csm_rmsnorm_bwd_blocks()
         parts = torch.empty(nb, d, dtype=F32, device=dev) if train_base else None
-        delta = torch.empty(B, H, S, dtype=F32, device=dev)
+        delta = torch.empty(2, B, H, S, dtype=F32, device=dev)   # attention-backward scratch (-delta, -lse log2e)
 
         def norm_bwd(x, name, rstd, dy, dres):
             dx = torch.empty(M, d, dtype=BF16, device=dev)

@@ -362,7 +362,7 @@ __device__ __forceinline__ void unrope2(const float* __restrict__ table, int p, 
 __global__ __launch_bounds__(256, 2) void attn64_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S, int H, int KV,
-                                                           float scale, const float* __restrict__ rope) {
+                                                           float scale, const float* __restrict__ rope, long long nstat /* B H S */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int rep = H / KV;
     const int nqblk = (S + 127) / 128;
@@ -393,8 +393,13 @@ __global__ __launch_bounds__(256, 2) void attn64_dq_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; ++j) dsum += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[j]);
     }
     const float my_delta = halves_sum(dsum);
-    if (h == 0 && qrow < S) delta[((size_t)b * H + hq) * S + qrow] = my_delta;
     const float nlse2 = -lse[((size_t)b * H + hq) * S + qc] * 1.4426950408889634f;
+    // published for the dK/dV kernel in the form it consumes them (it copies them to LDS by DMA, no arithmetic on the way):
+    // delta[0 .. nstat) = -delta, delta[nstat .. 2 nstat) = -lse * log2(e), each [B][H][S]
+    if (h == 0 && qrow < S) {
+        delta[((size_t)b * H + hq) * S + qrow] = -my_delta;
+        delta[(size_t)nstat + ((size_t)b * H + hq) * S + qrow] = nlse2;
+    }
 
     const unsigned sbase = (unsigned)(uintptr_t)smem;
     unsigned koff[4];                                    // row fragments of the K image; the V image's are + TILE
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn64_dq_kernel(const bf16_t* __restr
 // 64-query block, so two waves share each key half and their dK^T / dV^T accumulators are added through LDS at the end
 // (no atomics, a fixed order: deterministic).  The workgroup walks the 4 q-heads of the group x the query blocks at or
 // below the diagonal; Q and dO blocks arrive by LDS-DMA into a 3-stage ring (ONE image each, read by rows for S and dP and
-// transposed for dK^T and dV^T), lse and delta go through registers so that they land in LDS as -lse*log2(e) and -delta:
+// transposed for dK^T and dV^T), -lse*log2(e) and -delta (written in that form by the dQ kernel) arrive by LDS-DMA too:
 // the first is the addend of the exp2 argument, the second is read straight into the accumulators dP starts from.
 //   S = Q K^T, dP = dO V^T - delta (query on the register index, key on the lane)  ->  P = exp2(c S - lse), dS = P o dP
 //   dV^T += dO^T P, dK^T += Q^T dS   (P / dS leave their accumulators as the B operand, k = query)
@@ -553,9 +558,10 @@ __device__ __forceinline__ f32x4 stat_read(unsigned addr) {
     return v;
 }
 constexpr int KSTAGE = 2 * TILE + 512;      // Q image + dO image + 64 x (-lse*log2e) + 64 x (-delta)
+constexpr int KNSTAGE = 4;                  // ring depth of the dK/dV kernel: 66 KiB per workgroup, two workgroups per CU
 
 __global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            const float* __restrict__ nlse2 /* -lse log2e */, const float* __restrict__ ndelta /* -delta */,
                                                             bf16_t* __restrict__ dqkv, int S, int H, int KV, float scale,
                                                             const float* __restrict__ rope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -624,21 +630,21 @@ __global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __rest
     unsigned dma_q[2], dma_o[2];
     dma_lane_off(ld, wave, lane, dma_q);
     dma_lane_off(ldo, wave, lane, dma_o);
-    float streg = 0.f;                                   // one lse / delta value per thread (threads 0..127), a block ahead
+    // The block's 64 x (-lse log2e) and 64 x (-delta), written in that form by the dQ kernel, go to LDS by the same LDS-DMA
+    // as the tiles (4 bytes per lane: wave 0 the first row, wave 1 the second), so that no register - and with it no
+    // compiler-inserted wait on the freshly issued loads - sits between a request and its use two steps later.
     auto issue = [&](int it, int st) {
         const int hh = it / per_head, qb = kblk + it % per_head;
         const int hq = kvh * rep + hh;
         dma_tile(qkv + (size_t)b * S * ld + hq * 64, ld, S, qb * 64, smem + st * KSTAGE, wave, lane, dma_q);
         dma_tile(dout + (size_t)b * S * ldo + hq * 64, ldo, S, qb * 64, smem + st * KSTAGE + TILE, wave, lane, dma_o);
-        if (threadIdx.x < 128) {
-            int q = qb * 64 + (threadIdx.x & 63);
+        if (wave < 2) {
+            int q = qb * 64 + lane;
             q = q < S ? q : S - 1;
-            const size_t idx = ((size_t)b * H + hq) * S + q;
-            streg = threadIdx.x < 64 ? -lse[idx] * 1.4426950408889634f : -delta[idx];
+            const float* sp = (wave == 0 ? nlse2 : ndelta) + ((size_t)b * H + hq) * S + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(smem + st * KSTAGE + 2 * TILE + wave * 256), 4, 0, 0);
         }
-    };
-    auto commit_stats = [&](int st) {
-        if (threadIdx.x < 128) *reinterpret_cast<float*>(smem + st * KSTAGE + 2 * TILE + threadIdx.x * 4) = streg;
     };
 
     f32x16 dk0, dk1, dv0, dv1, zero16;
@@ -707,32 +713,40 @@ __global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __rest
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, KSTAGE>;
     using K2 = std::integral_constant<int, 2 * KSTAGE>;
+    using K3 = std::integral_constant<int, 3 * KSTAGE>;
     if (niter > 0) {
         issue(0, 0);
+        // (also the K^T / V^T fragments loaded above: naming them in an asm statement makes the compiler place ITS wait for those
+        //  loads here - left pending, it would put an s_waitcnt vmcnt(0) in front of the first MFMA of every tile)
+        asm volatile("" :: "v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
         VM_WAIT(0);
-        commit_stats(0);
         __builtin_amdgcn_s_barrier();
         fetch(K0{});                                     // the first tile's rows + stats (later ones ride under the previous tile)
         if (niter > 1) issue(1, 1);
+        if (niter > 2) issue(2, 2);
     }
-    // one query block per step: after the wait, the Q / dO images of blocks it and it+1 (DMA issued two / one step ago) and
-    // the stats of block it+1 (in registers) are complete; the stats are committed, the barrier publishes everything and
-    // releases the stage of block it-1, whose successor (block it+2) is then requested.  A tile reads block it and, at
-    // its end, prefetches from block it+1.
-#define KBLOCK(IT, SC_, SN_, NIDX, NNIDX)                                                                              \
+    // One query block per step, FOUR ring stages: a step is only one 32 x 32 tile per wave (16 MFMAs, well under a
+    // microsecond), so a block requested one step ahead would still be in flight when it is needed and every step would
+    // wait out the rest of a memory latency.  Block it+3 is requested at step it; at the top of step it the wait leaves the
+    // youngest request (block it+2: 4 LDS-DMA instructions per wave, plus the statistics row in waves 0-1) in flight and
+    // only requires block it+1 to have landed.  The barrier publishes that and releases the stage of block it-1, into which
+    // block it+3 goes.  A tile reads block it and, at its
+    // end, prefetches its fragments from block it+1.
+#define KBLOCK(IT, SC_, SN_, NNNIDX)                                                                                   \
     {                                                                                                                  \
-        VM_WAIT(0);                                                                                                    \
-        if ((IT) + 1 < niter) commit_stats(NIDX);                                                                      \
+        if ((IT) + 2 < niter) { if (wave < 2) { VM_WAIT(5); } else { VM_WAIT(4); } } else { VM_WAIT(0); }              \
         __builtin_amdgcn_s_barrier();                                                                                  \
-        if ((IT) + 2 < niter) issue((IT) + 2, NNIDX);                                                                  \
+        if ((IT) + 3 < niter) issue((IT) + 3, NNNIDX);                                                                 \
         tile(SC_{}, SN_{}, (kblk + (IT) % per_head) * 64 + 32 * qp);                                                   \
     }
-    for (int it = 0; it < niter; it += 3) {
-        KBLOCK(it, K0, K1, 1, 2)
+    for (int it = 0; it < niter; it += 4) {
+        KBLOCK(it, K0, K1, 3)
         if (it + 1 >= niter) break;
-        KBLOCK(it + 1, K1, K2, 2, 0)
+        KBLOCK(it + 1, K1, K2, 0)
         if (it + 2 >= niter) break;
-        KBLOCK(it + 2, K2, K0, 0, 1)
+        KBLOCK(it + 2, K2, K3, 1)
+        if (it + 3 >= niter) break;
+        KBLOCK(it + 3, K3, K0, 2)
     }
 #undef KBLOCK
 
@@ -808,16 +822,19 @@ int csm_attn64_dq_launch(const void* qkv, const void* out, const void* dout, con
     const int lds = NSTAGE * STAGE;
     dim3 grid((unsigned)(((S + 127) / 128) * H * B)), block(256);
     hipLaunchKernelGGL(attn64_dq_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta,
-                       (bf16_t*)dqkv, S, H, KV, scale, rope);
+                       (bf16_t*)dqkv, S, H, KV, scale, rope, (long long)B * H * S);
     return 0;
 }
 
 int csm_attn64_dkv_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
                           int KV, const float* rope, hipStream_t stream) {
     const float scale = 0.125f;
-    const int lds = NSTAGE * KSTAGE;
+    const int lds = KNSTAGE * KSTAGE;
+    static bool done = false;        // more than 64 KiB of dynamic LDS must be requested once
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn64_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
     dim3 grid((unsigned)(((S + 63) / 64) * KV * B)), block(256);
-    hipLaunchKernelGGL(attn64_dkv_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv,
-                       S, H, KV, scale, rope);
+    // (delta = the dQ kernel's output: [0, BHS) = -delta, [BHS, 2 BHS) = -lse log2e)
+    hipLaunchKernelGGL(attn64_dkv_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, delta + (size_t)B * H * S, delta,
+                       (bf16_t*)dqkv, S, H, KV, scale, rope);
     return 0;
 }

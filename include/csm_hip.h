@@ -121,7 +121,7 @@ int csm_set_attn_variant(int v); /* scheduling experiments: 0 = defaults; else b
                                   * tile and work order, heaviest-first order of the forward / dQ grid) - see attention.hip */
 int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                 float* delta_ws /* [B][H][S] */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
+                 float* delta_ws /* scratch, 2 x [B][H][S] floats */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 /* the same with the backward of csm_rope fused into the dQ / dK epilogues (table as for csm_rope, position = row index
  * inside the sequence): dqkv comes out as the gradient of the UN-rotated projection output, no separate inverse pass. */
 int csm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,

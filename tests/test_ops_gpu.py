@@ -480,7 +480,7 @@ def test_attention(dev, B, S, H, KV, hd):
     s = s.masked_fill(~torch.tril(torch.ones(S, S, dtype=torch.bool)), float("-inf"))
     close("attn lse", lse, torch.logsumexp(s, -1), 1e-3)
     dqkv = torch.zeros_like(qd)
-    delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    delta = torch.empty(2, B, H, S, dtype=torch.float32, device=dev)
     ops.attn_bwd(qd, out, dout.to(dev), lse, dqkv, delta, B, S, H, KV, hd)
     gq = qr.grad
     close("attn dq", dqkv[:, :H * hd], gq[:, :H * hd], 2e-2)

@@ -12,7 +12,7 @@ qkv = (torch.randn(B * S, (H + 2 * KV) * hd, device=dev, generator=g)).to(torch.
 dout = (torch.randn(B * S, H * hd, device=dev, generator=g)).to(torch.bfloat16)
 out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=dev)
 lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
+dqkv = torch.empty_like(qkv); delta = torch.empty(2, *lse.shape, dtype=lse.dtype, device=lse.device)
 fl = 4.0 * B * H * S * S / 2 * hd
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
