@@ -734,9 +734,11 @@ __global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __rest
     // end, prefetches its fragments from block it+1.
 #define KBLOCK(IT, SC_, SN_, NNNIDX)                                                                                   \
     {                                                                                                                  \
-        if ((IT) + 2 < niter) { if (wave < 2) { VM_WAIT(5); } else { VM_WAIT(4); } } else { VM_WAIT(0); }              \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        if ((IT) + 3 < niter) issue((IT) + 3, NNNIDX);                                                                 \
+        if (!AB_BAR) {                                                                                                 \
+            if ((IT) + 2 < niter) { if (wave < 2) { VM_WAIT(5); } else { VM_WAIT(4); } } else { VM_WAIT(0); }          \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            if ((IT) + 3 < niter) issue((IT) + 3, NNNIDX);                                                             \
+        }                                                                                                              \
         tile(SC_{}, SN_{}, (kblk + (IT) % per_head) * 64 + 32 * qp);                                                   \
     }
     for (int it = 0; it < niter; it += 4) {
