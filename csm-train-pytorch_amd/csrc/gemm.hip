@@ -132,46 +132,59 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 // Skinny product out[M][N] = alpha * X[M][K] . Wt[N][K]^T for N = 32 or 64 (a LoRA group's ranks): a pure bandwidth problem -
 // X is read once (M K 2 bytes), Wt (N K 2 bytes, tens of KB) stays in L2 - that a 128x128 GEMM tile serves badly (M / 128
 // workgroups, each walking K serially, 3/4 of every MFMA wasted).  Here a workgroup owns 16 rows and its four waves a quarter
-// of K each (M / 16 x 4 waves = 16 waves per CU at M = 16k: the latency of a short read-once stream is hidden by the number
-// of waves, not by depth); both operands are K-contiguous, so the MFMA fragments are plain 16-byte global loads into
-// registers (8 k-steps = 24-40 loads in flight per lane), no LDS until the four partial sums are added at the end.
+// of K each (M / 16 x 4 waves = 16 waves per CU at M = 16k).  X is fetched with fully coalesced instructions - two rows x 512
+// contiguous bytes per instruction - and turned into MFMA fragments through a wave-private LDS staging area (an MFMA fragment
+// read straight from global memory puts 16 rows, 4 KB apart, behind every instruction: measured 2.5 TB/s); the Wt
+// fragments, L2 residents, are read directly.  The four partial sums meet in LDS at the end, in a fixed order.
 template <int NT /* N / 16 */>
 __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, bf16_t* __restrict__ out,
                                                         int M, int K, int ldx, int ldw, int ldo, float alpha) {
-    __shared__ float red[3][NT][64][4];
+    constexpr int RS = 528;                                 // staged row: 512 B of k + 16 B pad (fragment reads hit 64 distinct banks)
+    __shared__ __attribute__((aligned(16))) char stage[4][16 * RS];
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int m0 = blockIdx.x * 16;
-    const int row = min(m0 + (lane & 15), M - 1);
     const int c = (lane >> 4) * 8;
     const int kbeg = kq * (K >> 2), kend = kbeg + (K >> 2);
-    const bf16_t* xp = X + (size_t)row * ldx + c;
     const bf16_t* wp = Wt + (size_t)(lane & 15) * ldw + c;
+    char* st = stage[kq];
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int U = NT == 2 ? 8 : 4;                      // k-steps of 32 per iteration
-    for (int k0 = kbeg; k0 < kend; k0 += 32 * U) {
-        bf16x8 fx[U], fw[U][NT];
+    for (int k0 = kbeg; k0 < kend; k0 += 256) {             // 256 k-values (8 k-steps of 32) per round; the last may be shorter
+        const int kn = min(256, kend - k0);                 // multiple of 32
+        U4 xr[8];
+        bf16x8 fw[8][NT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = min(k0 + 32 * u, kend - 32);      // (a short last iteration re-reads its final k-step; masked below)
-            fx[u] = *reinterpret_cast<const bf16x8*>(xp + k);
+        for (int i = 0; i < 8; ++i) {                       // instruction i: rows 2i, 2i+1, 32 lanes x 16 B each
+            const int r = min(m0 + 2 * i + (lane >> 5), M - 1);
+            const int kk = min((lane & 31) * 8, kn - 8);    // (lanes past a short round re-read its last chunk; never used)
+            xr[i] = *reinterpret_cast<const U4*>(X + (size_t)r * ldx + k0 + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + min(32 * u, kn - 32);
 #pragma unroll
             for (int j = 0; j < NT; ++j) fw[u][j] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(16 * j) * ldw + k);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k0 + 32 * u < kend) {
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<U4*>(st + (2 * i + (lane >> 5)) * RS + (lane & 31) * 16) = xr[i];
+        // (wave-private staging: a wave's own LDS operations execute in order, no barrier)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][j], fx[u], acc[j], 0, 0, 0);
+        for (int u = 0; u < 8; ++u)
+            if (32 * u < kn) {
+                const bf16x8 fx = *reinterpret_cast<const bf16x8*>(st + (lane & 15) * RS + u * 64 + (lane >> 4) * 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][j], fx, acc[j], 0, 0, 0);
             }
     }
     // lane holds out[m0 + (lane & 15)][16 j + 4 (lane >> 4) .. + 3]; add the four K quarters through LDS (fixed order)
+    __syncthreads();                                        // every wave is done with its staging area: reuse it
+    float* red = reinterpret_cast<float*>(&stage[0][0]);    // [3][NT][64][4]
     if (kq > 0) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[kq - 1][j][lane][r] = acc[j][r];
+            for (int r = 0; r < 4; ++r) red[(((kq - 1) * NT + j) * 64 + lane) * 4 + r] = acc[j][r];
     }
     __syncthreads();
     if (kq == 0 && m0 + (lane & 15) < M) {
@@ -179,7 +192,9 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const bf16_t* __restrict
         for (int j = 0; j < NT; ++j) {
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (((acc[j][r] + red[0][j][lane][r]) + red[1][j][lane][r]) + red[2][j][lane][r]) * alpha;
+            for (int r = 0; r < 4; ++r)
+                v[r] = (((acc[j][r] + red[((0 * NT + j) * 64 + lane) * 4 + r]) + red[((1 * NT + j) * 64 + lane) * 4 + r]) +
+                        red[((2 * NT + j) * 64 + lane) * 4 + r]) * alpha;
             uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
             *reinterpret_cast<uint2*>(out + (size_t)(m0 + (lane & 15)) * ldo + 16 * j + 4 * (lane >> 4)) = o;
         }
