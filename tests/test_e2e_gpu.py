@@ -342,6 +342,14 @@ def test_lora_fused_groups_match_per_adapter_path_and_oracle(dev):
         for j in range(len(G.adapters)):
             c0 = j * m.lora.r_pad
             assert float(G.gAt[:, c0 + 4:c0 + 8].abs().max()) == 0.0 and float(G.gBx[:, c0 + 4:c0 + 8].abs().max()) == 0.0, "rank padding"
+    # merging every adapter into its (possibly row-interleaved) frozen weight reproduces the adapted forward
+    from csm.training.lora import merge_lora_weights
+    with torch.no_grad():
+        before, _ = compute_loss(m, tokens, mask, targets)
+        merge_lora_weights(m)
+        m.lora = None
+        after, _ = compute_loss(m, tokens, mask, targets)
+    assert rel(after, before) < 2e-3, (float(after), float(before))
 
 
 def test_lora_rank4_mlp_adapters_and_trainer_step(dev, tmp_path):
