@@ -119,6 +119,39 @@ def test_gemm_256_many_tiles(dev):
         ops.lib.csm_set_gemm_variant(2)
 
 
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_256_persistent_rounds_with_residual(dev, mode):
+    """Several rounds of FULL 256x256 tiles per workgroup (the persistent form: the next tile's loads are requested before the
+    finished tile is stored and waited for with vmcnt counted past the epilogue's loads and stores) with a bf16 residual
+    that aliases the output (gradient accumulation, C += A.B) and without: same bits as one tile per workgroup."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 4096, 8192, 320                     # 512 tiles = 2 rounds; K = 5 K-tiles
+    if mode == "nt":
+        A, B, tA, tB = rnd((M, K), g), rnd((N, K), g), False, False
+    elif mode == "nn":
+        A, B, tA, tB = rnd((M, K), g), rnd((K, N), g), False, True
+    else:
+        A, B, tA, tB = rnd((K, M), g), rnd((K, N), g), True, True
+    Ad, Bd = A.to(dev), B.to(dev)
+    ref = (Ad.float().t() if tA else Ad.float()) @ (Bd.float() if tB else Bd.float().t())
+    R = rnd((M, N), g).to(dev)
+    out = {}
+    try:
+        for persistent in (1, 0):
+            ops.lib.csm_set_gemm256_persistent(persistent)
+            C = torch.empty(M, N, dtype=BF, device=dev)
+            ops.gemm(Ad, Bd, C, None, tA, tB)
+            acc = R.clone()
+            ops.gemm(Ad, Bd, acc, acc, tA, tB, alpha=0.5)             # in place: C = R + alpha * A.B with R == C
+            out[persistent] = (C, acc)
+    finally:
+        ops.lib.csm_set_gemm256_persistent(1)
+    close(f"persistent {mode}", out[1][0], ref, 1e-2)
+    close(f"persistent {mode} + R", out[1][1], 0.5 * ref + R.float(), 1e-2)
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
+
+
 def test_gemm_256_bitwise_repeatable(dev):
     from csm.hip import ops
     g = torch.Generator().manual_seed(77)
