@@ -484,6 +484,40 @@ def test_swiglu(dev):
         ops.lib.csm_set_gemm_variant(2)
 
 
+def test_swiglu_fused_epilogues_persistent_rounds(dev):
+    """The SwiGLU-forward and -backward GEMM epilogues over several rounds of full tiles per persistent workgroup (waits counted
+    past 32 / 64 epilogue memory operations): against the stand-alone kernels' arithmetic and bit-equal to one tile per workgroup."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(5)
+    M, F, D = 8192, 4096, 320                                            # fwd: 32 x 32 = 1024 tiles; bwd: 32 x 16 = 512 tiles
+    x, w13, w2 = rnd((M, D), g).to(dev), rnd((2 * F, D), g, 0.1).to(dev), rnd((D, F), g, 0.1).to(dev)
+    dout = rnd((M, D), g).to(dev)
+    res = {}
+    try:
+        for persistent in (1, 0):
+            ops.lib.csm_set_gemm256_persistent(persistent)
+            gu = torch.empty(M, 2 * F, dtype=BF, device=dev)
+            act = torch.empty(M, F, dtype=BF, device=dev)
+            ops.linear_swiglu_fwd(x, w13, gu, act)
+            dgu = torch.empty(M, 2 * F, dtype=BF, device=dev)
+            ops.linear_dx_swiglu_bwd(dout, w2, gu, dgu)
+            res[persistent] = (gu, act, dgu)
+    finally:
+        ops.lib.csm_set_gemm256_persistent(1)
+    gu, act, dgu = res[1]
+    close("gu", gu, x.float() @ w13.float().t(), 1e-2)
+    act2 = torch.empty(M, F, dtype=BF, device=dev)
+    ops.swiglu_fwd(gu, act2)
+    close("fused act vs stand-alone", act, act2.float(), 1.5e-2)      # (the fused form activates the fp32 sums, before their bf16 rounding)
+    dact = torch.empty(M, F, dtype=BF, device=dev)
+    ops.linear_dx(dout, w2, dact)
+    dgu2 = torch.empty(M, 2 * F, dtype=BF, device=dev)
+    ops.swiglu_bwd(gu, dact, dgu2)
+    close("fused dgu vs unfused", dgu, dgu2.float(), 2e-2)
+    for a_, b_ in zip(res[1], res[0]):
+        assert torch.equal(a_, b_)
+
+
 def _attn_ref(qkv, B, S, H, KV, hd):
     q = qkv[:, :H * hd].view(B, S, H, hd)
     k = qkv[:, H * hd:(H + KV) * hd].view(B, S, KV, hd)
