@@ -84,20 +84,23 @@ def _index_causal_mask(mask: torch.Tensor, input_pos: torch.Tensor):
 
 def llama3_rope_table(max_seq_len: int, head_dim: int, base: float, scale: float, low: float = 1.0, high: float = 4.0,
                       old_ctx: int = 8192) -> torch.Tensor:
-    """[P, hd/2, 2] (cos, sin) of the Llama-3 scaled frequencies (torchtune Llama3ScaledRoPE), fp32, on the host."""
-    out = []
-    for i in range(0, head_dim, 2):
-        f = 1.0 / (base ** (i / head_dim))
+    """[P, hd/2, 2] (cos, sin) of the Llama-3 scaled frequencies, fp32, built on the host the way torchtune 0.4.0's
+    ``Llama3ScaledRoPE`` builds its cache (the stacks of reference models/model.py:11-42): every step of the frequency
+    scaling is an fp32 tensor operation, not double arithmetic rounded at the end."""
+    one = torch.ones((), dtype=torch.float32)
+    freqs = one / (base ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    theta = torch.empty_like(freqs)
+    for i in range(freqs.numel()):
+        f = freqs[i]
         wl = 2 * math.pi / f
         if wl < old_ctx / high:
-            out.append(f)
+            theta[i] = f
         elif wl > old_ctx / low:
-            out.append(f / scale)
+            theta[i] = f / scale
         else:
             smooth = (old_ctx / wl - low) / (high - low)
-            out.append((1 - smooth) * f / scale + smooth * f)
-    theta = torch.tensor(out, dtype=torch.float64).to(torch.float32)
-    ang = torch.einsum("i,j->ij", torch.arange(max_seq_len, dtype=torch.float32), theta)
+            theta[i] = (1 - smooth) * f / scale + smooth * f
+    ang = torch.einsum("i,j->ij", torch.arange(max_seq_len, dtype=torch.float32), theta).float()
     return torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous()
 
 

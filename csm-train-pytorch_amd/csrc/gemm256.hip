@@ -195,7 +195,9 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     auto issueB = [&](int h, int rel, int tile, int b3) { if (ABL_G && tile >= 2) return; issue_half_pre(srcB, h, pb[h] + rel * srcB.step, slotB(b3, h)); };
     constexpr int NRA = (TA == 0) ? 4 : 8;     // LDS read instructions per prefetched A pair
     // the first two K-tiles of the output tile at (m0, n0): 8 + 8 (or 6) DMA instructions per wave
-    auto prologue = [&]() {
+    // ``a1`` : request A1 of K-tile 1 here as well (always for the EARLY layouts; for the others only in front of a later tile
+    // of a persistent workgroup, see ``a1_pre``)
+    auto prologue = [&](bool a1) {
         dma_prepare<TA>(A, g.lda, g.M, m0, srcA);
         dma_prepare<TB>(B, g.ldb, g.N, n0, srcB);
 #pragma unroll
@@ -203,11 +205,17 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         issueA(0, -2, 0, 0); issueA(1, -2, 0, 0); issueB(0, -2, 0, 0); issueB(1, -2, 0, 0);
         if (nt > 1) {
             issueB(0, -1, 1, 1); issueB(1, -1, 1, 1); issueA(0, -1, 1, 1);
-            if (EARLY) issueA(1, -1, 1, 1);
+            if (a1) issueA(1, -1, 1, 1);
         }
     };
-    prologue();
+    prologue(EARLY);
     int pend = 0;                               // memory operations of the previous tile's epilogue issued after the prologue
+    // Whether K-tile 1 is COMPLETE in the prologue (8 instructions) or lacks A1 (6; then ph1(0) requests it).  The counted
+    // waits past the previous tile's epilogue (``pend``) are only sound when everything the wait is for was requested BEFORE
+    // that epilogue: A1(1) requested in ph1(0) is younger than the stores, and `vmcnt(4 + pend)` at ph3(0) would not wait for
+    // it (round-2 race, tn layout: waves with a_half = 1 could read A half-tile 1 of K-tile 1 before it landed).  So later
+    // tiles of a workgroup always take the complete prologue.
+    bool a1_pre = EARLY;
   for (;;) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -215,8 +223,8 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // K-tile 0 has landed (K-tile 1's 8 / 6 instructions and ``pend`` younger operations may still be in flight)
     if (nt > 1) {
-        if (pend > 0 && EARLY) { const int w = min(63, 8 + pend); WAIT_VM_DYN(w); }
-        else if (EARLY) { WAIT_VM(8); } else { if (pend > 0) { WAIT_VM(0); } else { WAIT_VM(6); } }
+        if (a1_pre) { if (pend > 0) { const int w = min(63, 8 + pend); WAIT_VM_DYN(w); } else { WAIT_VM(8); } }
+        else { WAIT_VM(6); }                    // (first tile of a non-EARLY layout: pend == 0)
     } else { WAIT_VM(0); }
     BARRIER();
 
@@ -240,7 +248,7 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         const char* la = slotA(b, a_half);
         const char* lb = slotB(b3, b_half);
         // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
-        if (!EARLY && t + 1 < nt) issueA(1, -1, t + 1, b ^ 1);
+        if (!EARLY && t + 1 < nt && !(t == 0 && a1_pre)) issueA(1, -1, t + 1, b ^ 1);
         if (EARLYB && t + 2 < nt) issueB(0, 0, t + 2, b3n);
         if (!ABL_L) { fb.load(lb, b_off, lane);
         fa1.load(la, 32, lane); }
@@ -258,7 +266,8 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 4)
         WAIT_LGKM(0);                                           // pair-3 reads done: the A slots of this buffer are dead
-        // tile t+1 has landed (for t = 0 of a later tile of this workgroup, counted past the previous tile's stores)
+        // tile t+1 has landed (for t = 0 of a later tile of this workgroup, counted past the previous tile's stores: K-tile 1
+        // was requested in full before them, and only the two B halves of K-tile 2 - 4 instructions - after them)
         if (t + 2 < nt) { if (t == 0 && pend > 0) { const int w = min(63, 4 + pend); WAIT_VM_DYN(w); } else { WAIT_VM(4); } } else { WAIT_VM(0); }
         if (!ABL_B) BARRIER();
         // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
@@ -280,7 +289,12 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     const int em0 = m0, en0 = n0;
     id += stride;
     const bool more = id < nwg;
-    if (more) { coords(id, m0, n0); prologue(); }
+    if (more) {
+        coords(id, m0, n0); prologue(true); a1_pre = true;
+        // ``pend`` counts epilogue operations issued AFTER these requests: nothing of the epilogue may move above them
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     Epi e;
     e.C = reinterpret_cast<OutT*>(g.C) + (size_t)bz * g.sC;

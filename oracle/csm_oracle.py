@@ -131,13 +131,16 @@ def init_params(cfg: CsmCfg, seed: int = 0, std: float = 0.02, dtype=torch.float
 def llama3_inv_freq(head_dim: int, base: float = 500_000.0, scale: float = 32.0,
                     low_freq_factor: float = 1.0, high_freq_factor: float = 4.0,
                     old_context_len: int = 8192) -> torch.Tensor:
-    """torchtune ``Llama3ScaledRoPE`` frequency table (appendix A); float64 for table building."""
-    i = torch.arange(0, head_dim, 2, dtype=torch.float64)[: head_dim // 2]
-    freqs = 1.0 / (base ** (i / head_dim))
+    """torchtune 0.4.0 ``Llama3ScaledRoPE.rope_init`` + ``apply_scaling`` (appendix A), in the arithmetic torchtune
+    uses: ``freqs = 1 / base ** (arange(0, dim, 2)[:dim // 2].float() / dim)`` is an fp32 tensor, and the scaling loop
+    iterates over its 0-d fp32 elements, so the wavelength, the smoothing factor and the scaled frequency are all
+    rounded to fp32 at every operation (a float64 table differs from it in the last bit of some frequencies, which
+    is ~1e-4 rad at position 2047)."""
+    freqs = 1.0 / (base ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
     low_wl = old_context_len / low_freq_factor
     high_wl = old_context_len / high_freq_factor
     out = []
-    for f in freqs.tolist():
+    for f in freqs:                                    # 0-d fp32 tensors: python-scalar operands do not widen them
         wl = 2 * math.pi / f
         if wl < high_wl:
             out.append(f)
@@ -146,14 +149,15 @@ def llama3_inv_freq(head_dim: int, base: float = 500_000.0, scale: float = 32.0,
         else:
             smooth = (old_context_len / wl - low_freq_factor) / (high_freq_factor - low_freq_factor)
             out.append((1 - smooth) * f / scale + smooth * f)
-    return torch.tensor(out, dtype=torch.float64)
+    return torch.tensor([float(x) for x in out], dtype=freqs.dtype)
 
 
 def rope_table(max_seq_len: int, head_dim: int, base: float = 500_000.0, scale: float = 32.0) -> torch.Tensor:
-    """[max_seq_len, head_dim/2, 2] = (cos, sin)(pos * theta'), fp32 like torchtune's cache."""
-    theta = llama3_inv_freq(head_dim, base, scale).to(torch.float32)
-    pos = torch.arange(max_seq_len, dtype=torch.float32)
-    ang = torch.einsum("i,j->ij", pos, theta)
+    """[max_seq_len, head_dim/2, 2] = (cos, sin)(pos * theta'), fp32: torchtune's ``build_rope_cache``
+    (``seq_idx = arange(max_seq_len, dtype=theta.dtype)``, ``einsum('i, j -> ij', seq_idx, theta).float()``)."""
+    theta = llama3_inv_freq(head_dim, base, scale)
+    pos = torch.arange(max_seq_len, dtype=theta.dtype)
+    ang = torch.einsum("i,j->ij", pos, theta).float()
     return torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1)
 
 

@@ -152,6 +152,40 @@ def test_gemm_256_persistent_rounds_with_residual(dev, mode):
     assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
 
 
+@pytest.mark.parametrize("mode,M,N,K", [("tn", 16384, 2048, 8192), ("tn", 2048, 8192, 8192), ("nn", 8192, 8192, 2048), ("nt", 8192, 16384, 2048)])
+def test_gemm_256_persistent_long_contraction(dev, mode, M, N, K):
+    """The persistent form at the train step's own shapes (w13 / w2 weight gradients: 128 K-tiles, operands of 100-300 MB,
+    i.e. every K-tile comes from HBM, not from L2, so an LDS-DMA half-tile that is read before it has landed shows): same bits
+    as one tile per workgroup, three times over, with and without accumulation into an aliasing bf16 output."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(K + M)
+    if mode == "nt":
+        A, B, tA, tB = rnd((M, K), g), rnd((N, K), g), False, False
+    elif mode == "nn":
+        A, B, tA, tB = rnd((M, K), g), rnd((K, N), g), False, True
+    else:
+        A, B, tA, tB = rnd((K, M), g), rnd((K, N), g), True, True
+    Ad, Bd = A.to(dev), B.to(dev)
+    R = rnd((M, N), g).to(dev)
+    out = {}
+    try:
+        for persistent in (0, 1, 1, 1):
+            ops.lib.csm_set_gemm256_persistent(persistent)
+            C = torch.empty(M, N, dtype=BF, device=dev)
+            ops.gemm(Ad, Bd, C, None, tA, tB)
+            acc = R.clone()
+            ops.gemm(Ad, Bd, acc, acc, tA, tB, alpha=0.5)
+            if persistent == 0:
+                out[0] = (C, acc)
+            else:
+                assert torch.equal(C, out[0][0]), f"{mode}: persistent != one tile per workgroup"
+                assert torch.equal(acc, out[0][1]), f"{mode}: persistent != one tile per workgroup (accumulating)"
+    finally:
+        ops.lib.csm_set_gemm256_persistent(1)
+    ref = (Ad.float().t() if tA else Ad.float()) @ (Bd.float() if tB else Bd.float().t())
+    close(f"long-K {mode}", out[0][0], ref, 1e-2)
+
+
 def test_gemm_256_bitwise_repeatable(dev):
     from csm.hip import ops
     g = torch.Generator().manual_seed(77)
