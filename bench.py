@@ -41,10 +41,45 @@ def parse():
     ap.add_argument("--lora", action="store_true", help="configs[2]: LoRA r=8 q_proj/v_proj instead of full-param")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048, help="positions of the CPU-baseline sample (SURVEY 8d protocol: B=1, S=2048)")
-    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
+    ap.add_argument("--cpu-budget", type=float, default=270.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (loss modes A / B, LoRA B=8, generate 10 s)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only; the number is not the metric)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous plumbing only (gloo on the CPU, no model, no GPU): what tests/test_cpu.py runs")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """``--gpus N`` (N > 1) without a torchrun environment: start the N ranks ourselves, one process per GPU, as
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>``
+    - children, never an exec, and before this process has touched the GPU - forward rank 0's single JSON line and exit
+    non-zero if any rank did.  The line must say ``n_gpus == N`` and name N ranks, or the run fails: an N-GPU request must
+    never silently measure one GPU."""
+    import socket
+    import subprocess
+    if not a.dry_run and "CSM_BENCH_FORCE_DEVICE" not in os.environ:
+        have = torch.cuda.device_count()          # counts without initialising the GPU runtime
+        if have < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)            # stderr passes through
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit(f"bench.py --gpus {a.gpus}: a rank failed (torch.distributed.run exit code {proc.returncode})")
+    if len(lines) != 1:
+        sys.stderr.write(proc.stdout)
+        raise SystemExit(f"bench.py --gpus {a.gpus}: expected ONE JSON line from rank 0, got {len(lines)}")
+    out = json.loads(lines[0])
+    ranks = (out.get("rccl") or {}).get("world")
+    if out.get("n_gpus") != a.gpus or ranks != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: the result line reports n_gpus={out.get('n_gpus')}, rccl.world={ranks}")
+    print(lines[0], flush=True)
 
 
 class GemmTimer:
@@ -53,6 +88,11 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
+
+    def _kernel(self):
+        """rocprofv3's name of the kernel the library just launched (csm_gemm_last_kernel), 'unsigned short' spelled u16."""
+        from csm.hip import lib
+        return lib.csm_gemm_last_kernel().decode().replace("unsigned short", "u16")
 
     def __enter__(self):
         from csm.hip import ops
@@ -68,14 +108,14 @@ class GemmTimer:
             e0.record(); timer.orig_fwd(x, w13, gu, act); e1.record()
             M, K = x.shape
             N = w13.shape[0]
-            timer.records.append(("nt_fwd_bf16", 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N + M * N // 2)))
+            timer.records.append(("nt_fwd_bf16", 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N + M * N // 2), timer._kernel()))
 
         def fused_bwd(dy, w2, gu, dgu):           # dgu[M,2F] = SwiGLU'(gu) . (dy w2) in the epilogue
             e0, e1 = ev()
             e0.record(); timer.orig_bwd(dy, w2, gu, dgu); e1.record()
             M, K = dy.shape
             F = w2.shape[1]
-            timer.records.append(("nn_dgrad_bf16", 2.0 * M * F * K, e0, e1, 2.0 * (M * K + F * K + 4 * M * F)))
+            timer.records.append(("nn_dgrad_bf16", 2.0 * M * F * K, e0, e1, 2.0 * (M * K + F * K + 4 * M * F), timer._kernel()))
 
         def timed(A, B, C, R=None, transA=False, transB=False, alpha=1.0, batch=1, sA=0, sB=0, sC=0, sR=0):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -87,7 +127,7 @@ class GemmTimer:
             kind = {(False, False): "nt_fwd", (False, True): "nn_dgrad", (True, True): "tn_wgrad", (True, False): "tt"}[(transA, transB)]
             kind += "_f32" if C.dtype == torch.float32 else "_bf16"
             esz = C.element_size()
-            timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1, batch * (2.0 * (M * K + N * K) + esz * M * N)))
+            timer.records.append((kind, 2.0 * M * N * K * batch, e0, e1, batch * (2.0 * (M * K + N * K) + esz * M * N), timer._kernel()))
             return out
 
         self.orig_rope = ops.linear_rope_fwd
@@ -97,7 +137,7 @@ class GemmTimer:
             e0.record(); r = timer.orig_rope(x, w, out, table, S, n_rope_cols, head_dim); e1.record()
             M, K = x.shape
             N = w.shape[0]
-            timer.records.append(("nt_fwd_bf16", 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
+            timer.records.append(("nt_fwd_bf16", 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N), timer._kernel()))
             return r
 
         ops.linear_rope_fwd = fused_rope
@@ -118,7 +158,7 @@ class GemmTimer:
             if ok:
                 M = dy1.shape[0]
                 fl = 2.0 * M * (dw1.numel() + dw2.numel())
-                timer.records.append(("tn_wgrad_bf16", fl, e0, e1, 2.0 * (dy1.numel() + x1.numel() + dy2.numel() + x2.numel() + dw1.numel() + dw2.numel())))
+                timer.records.append(("tn_wgrad_bf16", fl, e0, e1, 2.0 * (dy1.numel() + x1.numel() + dy2.numel() + x2.numel() + dw1.numel() + dw2.numel()), timer._kernel()))
             return ok
 
         ops.two_linear_dw = two_dw
@@ -130,7 +170,7 @@ class GemmTimer:
             M, K = A.shape
             N = B.shape[1] if transB else B.shape[0]
             timer.records.append(("nn_dgrad_bf16" if transB else "nt_fwd_bf16", 2.0 * M * N * (K + xA.shape[1]), e0, e1,
-                                  2.0 * (M * K + N * K + C.numel() + xA.numel() + xB.numel())))
+                                  2.0 * (M * K + N * K + C.numel() + xA.numel() + xB.numel()), timer._kernel()))
             return r
 
         ops.gemm_kext = kext
@@ -164,28 +204,31 @@ class GemmTimer:
                 "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBPS, 4), "ms_per_step": round(sec * 1e3, 3),
                 "algorithmic_bytes_per_step": nbytes}
 
-    def summary(self):
+    def summary(self, by_kernel=False):
+        """Per GEMM kind (operand layout x output type) or, ``by_kernel``, per kernel symbol as rocprofv3 names it."""
         torch.cuda.synchronize()
         agg = {}
-        for kind, flop, e0, e1, nbytes in self.records:
-            d = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
+        for kind, flop, e0, e1, nbytes, kernel in self.records:
+            d = agg.setdefault(kernel if by_kernel else kind, [0.0, 0.0, 0, 0.0, {}])
             d[0] += flop
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
             d[3] += nbytes
+            other = kind if by_kernel else kernel
+            d[4][other] = d[4].get(other, 0) + 1
         return {k: {"tflops": v[0] / v[1] / 1e12, "time_ms": v[1] * 1e3, "launches": v[2], "avg_us": v[1] / v[2] * 1e6,
-                    "flop": v[0], "operand_bytes_per_launch": v[3] / v[2]} for k, v in agg.items() if v[1] > 0}
+                    "flop": v[0], "operand_bytes_per_launch": v[3] / v[2], "split": v[4]} for k, v in agg.items() if v[1] > 0}
 
 
-def pmc_traffic(kind):
-    """HBM-side bytes per launch of a GEMM kind from the committed rocprofv3 PMC passes over this same command
-    (profiles/run_pmc_bench_rNN.sh -> the newest profiles/rNN_bench_pmc_traffic.json); None when there is none.  Counters
-    cannot be read from inside the timed process, so this is the profile's figure, not a live one."""
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of a GEMM kernel (rocprofv3 symbol) from the committed rocprofv3 PMC passes over this same
+    command (profiles/run_pmc_bench_rNN.sh -> the newest profiles/rNN_bench_pmc_traffic.json); None when there is none.
+    Counters cannot be read from inside the timed process, so this is the profile's figure, not a live one."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
     if not files:
         return None, None
-    t = json.load(open(files[-1])).get(kind)
+    t = json.load(open(files[-1])).get("_kernels", {}).get(kernel)
     if not t:
         return None, None
     return t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
@@ -261,20 +304,74 @@ def cpu_baseline(model, cfg_fn, seq, seed, sw, aw, budget_s):
                 loss=loss0), (tokens, mask, targets)
 
 
+def comm_census(world, backend, local):
+    """Who is in the job: every rank reports (rank, device index, device name) through the process group itself, so the
+    result line proves that N ranks on N different GPUs took part in the collectives (the driver reads ``rccl.world``)."""
+    import torch.distributed as dist
+    me = {"rank": int(os.environ.get("RANK", 0)), "device": local, "name": torch.cuda.get_device_name(local)}
+    if world == 1:
+        return {"world": 1, "backend": None, "devices": [local]}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    ones = torch.ones(1, device="cuda")
+    dist.all_reduce(ones)                                            # a real device collective: RCCL carries it when backend == nccl
+    devices = [e["device"] for e in sorted(everyone, key=lambda e: e["rank"])]
+    if int(ones.item()) != world:
+        raise SystemExit(f"bench.py: the all-reduce saw {int(ones.item())} ranks, WORLD_SIZE={world}")
+    if len(set(devices)) != world and "CSM_BENCH_FORCE_DEVICE" not in os.environ:
+        raise SystemExit(f"bench.py: {world} ranks but devices {devices}: two ranks share a GPU")
+    return {"world": world, "backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "devices": devices,
+            "ranks_in_allreduce": int(ones.item())}
+
+
+def dry_run(a, rank, world, real_stdout):
+    """The launcher's contract without a GPU: rendezvous (gloo), barrier, MAX over ranks of a timed region, one JSON line
+    from rank 0 that names the ranks.  Not a measurement."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.ones(1)
+    for _ in range(a.steps):
+        if world > 1:
+            dist.all_reduce(x)
+            x /= world
+    t = torch.tensor([time.perf_counter() - t0])
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher plumbing only, no model, no GPU)", "value": 0.0, "unit": "tokens/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(t) / max(1, a.steps) * 1e3, "dry_run": True,
+                          "rccl": {"world": int(seen.item()), "backend": "gloo (dry run)"}}), file=real_stdout, flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE line (the JSON result): everything incidental - logger handlers created from here on,
     # library prints - goes to stderr
     real_stdout, sys.stdout = sys.stdout, sys.stderr
+    if a.gpus < 1:
+        raise SystemExit(f"--gpus {a.gpus}")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.stdout = real_stdout
+        return launch_ranks(a)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if "CSM_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the multi-rank path on a one-GPU box (with gloo)
         local = int(os.environ["CSM_BENCH_FORCE_DEVICE"])
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
+    if world != a.gpus:                             # a launcher that started a different number of ranks than --gpus says
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    backend = None
+    if a.dry_run:
+        return dry_run(a, rank, world, real_stdout)
+    torch.cuda.set_device(local)
     if world > 1:
         backend = os.environ.get("CSM_BENCH_BACKEND", "nccl")        # nccl == RCCL on ROCm
         if backend == "nccl":
@@ -282,6 +379,7 @@ def main():
             init_nccl(rank, world, local)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    rccl = comm_census(world, backend, local)
 
     from csm.data import SyntheticCSMDataset, collate_variable_length
     from csm.models.model import Model, ModelArgs
@@ -393,12 +491,13 @@ def main():
         per_step = res["per_step"]
         pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)   # noqa: E731
         kinds, gemm_flop, att_flop = step_flops(model, res)
-        bf = {k: v for k, v in kinds.items() if k.endswith("_bf16")}
-        dom = max(bf.items(), key=lambda kv: kv[1]["time_ms"]) if bf else (None, None)
+        # the dominant kernel = the kernel SYMBOL (as rocprofv3 prints it) with the most time in the instrumented step
+        kernels = res["gt"].summary(by_kernel=True) if res["gt"] is not None else {}
+        dom = max(kernels.items(), key=lambda kv: kv[1]["time_ms"]) if kernels else (None, None)
         roof = None
         if dom[0] is not None:
             traffic, traffic_src = pmc_traffic(dom[0]) if (a.batch, a.seq, a.mode, a.lora, a.tiny) == (4, 2048, "C", False, False) else (None, None)
-            roof = {"bound": "mfma", "kernel": f"gemm_kernel<{dom[0]}>", "achieved": round(dom[1]["tflops"], 2),
+            roof = {"bound": "mfma", "kernel": dom[0], "kinds": dom[1]["split"], "achieved": round(dom[1]["tflops"], 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                     "operand_bytes_per_launch": round(dom[1]["operand_bytes_per_launch"]),
@@ -406,8 +505,10 @@ def main():
                                  "register-only MFMA loop reaches 1.56-1.85 PFLOP/s on random bf16 operands (tools/probes/mfma_shape_probe.hip, "
                                  "profiles/r02_clock_power.txt)",
                     "avg_launch_us": round(dom[1]["avg_us"], 2), "launches_per_step": dom[1]["launches"],
+                    "all_gemm_kernels": {k: {"tflops": round(v["tflops"], 1), "ms_per_step": round(v["time_ms"], 2),
+                                             "launches": v["launches"]} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["time_ms"])},
                     "all_gemm_variants": {k: {"tflops": round(v["tflops"], 1), "ms_per_step": round(v["time_ms"], 2),
-                                              "launches": v["launches"]} for k, v in kinds.items()}}
+                                              "launches": v["launches"], "kernels": v["split"]} for k, v in kinds.items()}}
         out = {
             "metric": "train tokens/sec (text+audio) CSM-1B bf16 seq2048", "value": round(tokens_per_s, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -423,6 +524,7 @@ def main():
             "step_flop": {"gemm": gemm_flop, "attention": att_flop},
             "hbm_kernel": gt.adamw_summary() if gt is not None else None,
             "loss": float(loss), "step_ms": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}, "roofline": roof,
+            "rccl": rccl,
         }
         if exposed is not None:
             out["exposed_comm_ms"] = {"mean": round(sum(exposed) / len(exposed), 3), "max": round(max(exposed), 3),

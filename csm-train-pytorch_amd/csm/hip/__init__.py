@@ -37,6 +37,9 @@ _SIGS = {
     "csm_gemm_bf16_two_wgrad": ([_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "csm_set_gemm_variant": ([_i], _i),
     "csm_set_gemm256_persistent": ([_i], _i),
+    "csm_get_gemm256_persistent": ([], _i),
+    "csm_gemm_last_kernel": ([], C.c_char_p),
+    "csm_attn_bwd_workspace_bytes": ([_i, _i, _i], _ll),
     "csm_rmsnorm_fwd": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
     "csm_rmsnorm_bwd_blocks": ([], _i),
     "csm_rmsnorm_bwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _p], _i),

@@ -252,7 +252,8 @@ def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, S, H, KV, HD, rope_table=No
     """dqkv = gradient of the (rotated) q | k | v rows; with ``rope_table`` the RoPE backward is applied in the dQ / dK
     epilogues and dqkv is the gradient of the un-rotated projection output (positions = row index in the sequence)."""
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
-    assert delta_ws.dtype == torch.float32 and delta_ws.is_contiguous() and delta_ws.numel() >= 2 * B * H * S, "delta_ws: 2 x [B,H,S] floats of scratch"
+    need = lib.csm_attn_bwd_workspace_bytes(B, S, H)
+    assert delta_ws.dtype == torch.float32 and delta_ws.is_contiguous() and delta_ws.numel() * 4 >= need, f"delta_ws: {need} bytes of scratch"
     if rope_table is None:
         check(lib.csm_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
                                delta_ws.data_ptr(), B, S, H, KV, HD, _stream()), "csm_attn_bwd")

@@ -360,7 +360,20 @@ class Model(nn.Module):
                 raise RuntimeError(f"load_state_dict: shape mismatch for {k}: {tuple(v.shape)} vs {tuple(dst.shape)}")
             dst.copy_(v.to(device=dst.device, dtype=dst.dtype))
         self._fp32_source = {k: v for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype == torch.float32} or None
+        self.params_rewritten(base=any(k in views for k in state_dict), lora=any(k in lora_names for k in state_dict))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def params_rewritten(self, base: bool = True, lora: bool = True):
+        """Tell every live optimiser built on this model that the working weights changed underneath it (its fp32 master
+        is partly stored IN the bf16 arena: training/optim.py)."""
+        alive = []
+        for ref in getattr(self, "_optimizers", []):
+            opt = ref()
+            if opt is not None:
+                opt.params_rewritten(base, lora)
+                alive.append(ref)
+        if hasattr(self, "_optimizers"):
+            self._optimizers = alive
 
     # ------------------------------------------------------------------ helpers shared with the engine
     def rope_table(self, which: str) -> torch.Tensor:

@@ -77,6 +77,10 @@ class GradSync:
         self.timing = False                       # record how long the compute stream waits for the collectives (bench.py)
         self.exposed_ms: List[float] = []
         self._wait_events: List[tuple] = []
+        self.opt_step = 0                         # optimiser steps whose collectives have been launched
+        self.skipped_steps: List[int] = []        # optimiser steps dropped on every rank (text-row exchange over capacity)
+        self.on_skip: List[Callable[[int], None]] = []   # called with the step index once the host has seen the flag
+        self._restore_persistent: Optional[int] = None
 
     @staticmethod
     def active() -> bool:
@@ -109,7 +113,7 @@ class GradSync:
             cap = int(os.environ.get("CSM_DP_TEXT_ROWS_CAP", cls.TEXT_ROWS_CAP))
             sparse = dict(slice=(t.offset, t.numel), D=model.bb.embed_dim, seen=[], cap=cap, n_rows=t.shape[0],
                           overflow=torch.zeros(1, dtype=torch.int32, device=model.grad_arena.device),
-                          host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=None)
+                          pending=[])      # (optimiser step, event, pinned int32[1]) per exchange, oldest first
         merged = {k: cls._merge(v) for k, v in buckets.items()}
         extra = [model.lora.grad_arena] if model.lora is not None else []
         gs = cls(model.grad_arena, merged, group, extra)
@@ -119,9 +123,27 @@ class GradSync:
             # with a fixed tile list each, so the workgroups that find their CU taken would run their whole list late; one tile
             # per workgroup lets the dispatcher pack the remaining CUs instead.  (Single-GPU runs keep the persistent form.)
             from ..hip import lib
+            import logging
+            gs._restore_persistent = lib.csm_get_gemm256_persistent()
             lib.csm_set_gemm256_persistent(0)
+            logging.getLogger("csm_trainer").info(
+                "data parallel: 256x256 GEMM switched from persistent workgroups to one tile per workgroup while gradient "
+                "collectives share the CUs (CSM_GEMM256_PERSISTENT pins it; GradSync.close() restores the previous setting)")
         model.engine.grad_hook = gs.on_ready
+        gs._model = model
         return gs
+
+    def close(self):
+        """End of data-parallel training in this process: detach from the engine, look at every outstanding overflow flag and
+        give the process-global GEMM schedule switch back (a later single-GPU model in the same process must not inherit it)."""
+        self.check_overflow(block=True)
+        m = getattr(self, "_model", None)
+        if m is not None and getattr(m.engine, "grad_hook", None) == self.on_ready:
+            m.engine.grad_hook = None
+        if self._restore_persistent is not None:
+            from ..hip import lib
+            lib.csm_set_gemm256_persistent(self._restore_persistent)
+            self._restore_persistent = None
 
     @staticmethod
     def _merge(slices: List[Tuple[int, int]]) -> List[Tuple[int, int]]:
@@ -147,27 +169,58 @@ class GradSync:
         mk = masks[..., k].reshape(-1).to(self.flat.device, non_blocking=True).bool()
         sp["seen"].append(torch.where(mk, t, torch.full_like(t, sp["n_rows"])))
 
+    OVERFLOW_LAG = 2      # optimiser steps between an exchange and the host's look at its flag (see check_overflow)
+
     def arm(self, enabled: bool = True):
         """Call before a backward: ``enabled`` only on the micro-batch that ends an accumulation window."""
         self.armed = enabled and self.world_size > 1
         self.done = set()
         self.handles = []
+        self.check_overflow(block=False)
+
+    def skip_flag(self) -> Optional[torch.Tensor]:
+        """Device int32[1]: non-zero when the step whose collectives just finished must be dropped (the same value on every
+        rank).  Valid on the compute stream after ``finish()``; hand it to ``FusedAdamW.step(skip=...)``."""
+        return self.sparse["overflow"] if self.sparse is not None else None
+
+    def check_overflow(self, block: bool):
+        """Look at the overflow flags of past text-row exchanges.
+
+        The flag of step k is all-reduced (MAX) on the device, applied on the device (the optimiser step k is dropped on every
+        rank: ``skip_flag``), and copied to its own pinned slot - never overwritten, so no flag is lost however far the host
+        runs ahead.  The host reads it at a FIXED distance: ``arm`` of step k + OVERFLOW_LAG waits for step k's copy (by then
+        it completed long ago: the host never runs two steps ahead of the device, so the wait costs nothing), and
+        ``block=True`` (before a checkpoint, at the end of an epoch, in ``close``) drains every outstanding one.  A fixed
+        distance matters: the reaction - doubling the capacity - changes the size of the next all-gather and must happen at
+        the same step on every rank; ``event.query()`` would make it depend on each host's timing."""
         sp = self.sparse
-        if sp is not None and sp["event"] is not None and sp["event"].query():
-            # the previous step's overflow flag has reached the host (asynchronous copy): look at it without waiting
-            sp["event"] = None
-            if int(sp["host"][0]) > 0:
-                raise RuntimeError(
-                    f"data-parallel text-embedding exchange: a rank touched more than {sp['cap']} distinct text rows in one "
-                    "optimiser step, the previous step's embedding gradients are incomplete.  Raise CSM_DP_TEXT_ROWS_CAP or set "
-                    "CSM_DP_DENSE_EMBEDDINGS=1 (dense 525 MB all-reduce).")
+        if sp is None:
+            return
+        while sp["pending"] and (block or sp["pending"][0][0] <= self.opt_step - self.OVERFLOW_LAG):
+            step, event, host = sp["pending"].pop(0)
+            event.synchronize()
+            if int(host[0]) > 0:
+                self._on_overflow(step)
+
+    def _on_overflow(self, step: int):
+        import logging
+        sp = self.sparse
+        old = sp["cap"]
+        sp["cap"] = min(sp["n_rows"], 2 * old)
+        self.skipped_steps.append(step)
+        for cb in self.on_skip:
+            cb(step)
+        logging.getLogger("csm_trainer").warning(
+            f"data parallel: optimiser step {step} touched more than {old} distinct text-embedding rows on some rank; the step "
+            f"was dropped on every rank (weights and moments untouched, replicas identical) and the exchange capacity is now "
+            f"{sp['cap']} rows (CSM_DP_TEXT_ROWS_CAP sets the start value, CSM_DP_DENSE_EMBEDDINGS=1 the dense all-reduce)")
 
     def _launch_text_rows(self):
         """Fixed-capacity exchange of the touched text-embedding gradient rows: every rank sends ``cap`` (row id, gradient
         row) slots (id -1 = unused), all-gathers everybody's, and adds them in rank order - bit-identical tables on every
         rank, as after an all-reduce, for a few MB instead of 525.  Every size is static, so nothing here waits for the
-        host: an overflow (more than ``cap`` distinct rows on some rank) raises a device flag that ``arm`` reads a step
-        later through an asynchronous copy."""
+        host: an overflow (more than ``cap`` distinct rows on some rank) raises a device flag that drops the optimiser step
+        on every rank (``skip_flag``) and that the host reads two steps later (``check_overflow``)."""
         from ..hip import ops
         sp = self.sparse
         o, n = sp["slice"]
@@ -200,9 +253,11 @@ class GradSync:
             for r in range(self.world_size):                                     # fixed order: every rank computes the same bits
                 ops.rows_add_bf16(g, all_r[r * cap:(r + 1) * cap], all_g[r * cap:(r + 1) * cap], 1)
             dist.all_reduce(sp["overflow"], op=dist.ReduceOp.MAX, group=self.group)
-            sp["host"].copy_(sp["overflow"], non_blocking=True)
-            sp["event"] = torch.cuda.Event()
-            sp["event"].record()
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()               # this step's own slot: nothing overwrites it
+            host.copy_(sp["overflow"], non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            sp["pending"].append((self.opt_step, event, host))
 
     def _all_gather(self, out: torch.Tensor, part: torch.Tensor):
         """out = concatenation over the ranks of ``part`` (one flat collective on RCCL; the list form where the backend -
@@ -262,6 +317,7 @@ class GradSync:
             for h in self.handles:
                 h.wait()
         self.armed = False
+        self.opt_step += 1
 
     def exposed_comm_ms(self) -> List[float]:
         """Per optimiser step: how long the compute stream sat waiting for the communication stream at the end of the
@@ -282,6 +338,8 @@ class GradSync:
         dist.broadcast(model.arena, src=src, group=group)
         if model.lora is not None:
             dist.broadcast(model.lora.arena, src=src, group=group)
+        if hasattr(model, "params_rewritten"):
+            model.params_rewritten() # an optimiser built earlier keeps part of its fp32 master IN these weights (optim.py)
 
     @staticmethod
     def assert_replicas_equal(model, group=None, what: str = "parameters"):

@@ -303,4 +303,5 @@ def merge_lora_weights(model):
         sub = "attn" if mod in ATTN else "mlp"
         W = views[f"{prefix}.layers.{i}.{sub}.{mod}.weight"]
         ops.gemm(ad.B, ad.At, W, W, False, False, alpha=lo.scaling)
+    model.params_rewritten(lora=False)        # an optimiser over the base weights must not keep the old lower halves
     return model

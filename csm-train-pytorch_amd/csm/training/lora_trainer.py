@@ -204,6 +204,7 @@ class CSMLoRATrainer:
             merge_lora_weights(self.model)
             sd = {k: v.detach().cpu().contiguous() for k, v in self.model._views(self.model.arena).items()}
             self.model.arena.copy_(backup)
+            self.model.params_rewritten(lora=False)
             save_file(sd, path)
         return base
 

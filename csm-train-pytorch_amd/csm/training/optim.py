@@ -57,27 +57,37 @@ class FusedAdamW:
             self.param_groups.append(dict(name="lora", lr=float(lora_lr), weight_decay=lora_weight_decay, offset=0,
                                           numel=lo.arena.numel(), param=lo.arena, grad=lo.grad_arena))
         for g in self.param_groups:
-            p = g["param"]
-            master = p.float()
-            src = getattr(model, "_fp32_source", None)
-            if src and g["name"] != "lora":
-                # a checkpoint loaded in fp32 seeds the master copy at full precision
-                views, base = model._views(model.arena), model.arena.storage_offset()
-                for k, t in src.items():
-                    v = views.get(k)
-                    if v is None:
-                        continue
-                    so = v.storage_offset() - base
-                    if g["offset"] <= so < g["offset"] + g["numel"]:
-                        torch.as_strided(master, v.size(), v.stride(), so - g["offset"]).copy_(t.to(master.device))
+            master = self._seed_master(g)
             if SPLIT_MASTER:
-                lo = split_master(master, p)          # the working copy becomes the master's (half-up rounded) upper half
+                lo = split_master(master, g["param"])  # the working copy becomes the master's (half-up rounded) upper half
                 self.state[g["name"]] = dict(lo=lo, m=torch.zeros_like(master), v=torch.zeros_like(master))
                 del master
             else:
                 self.state[g["name"]] = dict(master=master, m=torch.zeros_like(master), v=torch.zeros_like(master))
         self._partials = torch.empty(max(1, len(self.param_groups)) * ops.sumsq_blocks(), dtype=F32, device=model.device)
         self._norm_coef = torch.ones(2, dtype=F32, device=model.device)
+        # the model tells its optimisers when somebody rewrites the working weights behind their back (params_rewritten)
+        import weakref
+        if not hasattr(model, "_optimizers"):
+            model._optimizers = []
+        model._optimizers.append(weakref.ref(self))
+
+    def _seed_master(self, g) -> torch.Tensor:
+        """fp32 master of a group from the current bf16 working weights; a state dict loaded in fp32 (``Model._fp32_source``)
+        seeds its parameters at full precision."""
+        model, p = self.model, g["param"]
+        master = p.float()
+        src = getattr(model, "_fp32_source", None)
+        if src and g["name"] != "lora":
+            views, base = model._views(model.arena), model.arena.storage_offset()
+            for k, t in src.items():
+                v = views.get(k)
+                if v is None:
+                    continue
+                so = v.storage_offset() - base
+                if g["offset"] <= so < g["offset"] + g["numel"]:
+                    torch.as_strided(master, v.size(), v.stride(), so - g["offset"]).copy_(t.to(master.device))
+        return master
 
     def named_master(self):
         """(reference parameter name, fp32 master view) for every trainable base parameter."""
@@ -139,13 +149,22 @@ class FusedAdamW:
         self._coef = self._norm_coef
         return self._norm_coef[0]
 
-    def step(self, zero_grad=False):
+    def step(self, zero_grad=False, skip: Optional[torch.Tensor] = None):
         """One AdamW update.  ``zero_grad=True`` clears the gradients in the same pass over memory.  ``zero_grad="lazy"``
         (what the trainers use) clears only the embedding tables, whose backward is a scatter-add that needs zeros
         underneath; the dense groups are marked stale instead and the next backward OVERWRITES them - their weight-gradient
-        GEMMs then skip the read of the old value and nobody writes 2 bytes per parameter of zeros."""
+        GEMMs then skip the read of the old value and nobody writes 2 bytes per parameter of zeros.
+
+        ``skip``: a device int32 tensor; non-zero means "drop this step" (weights and moments untouched, gradients cleared
+        as ``zero_grad`` says).  The decision stays on the device - it travels to the kernels as a negative clip coefficient -
+        so the host launches the same work either way (training/dp.py: text-row exchange over capacity).  The caller
+        un-counts a dropped step with ``uncount_step`` once the host has seen the flag."""
         self._settle()
         self.step_count += 1
+        if skip is not None:
+            coef = self._coef[1] if self._coef is not None else torch.ones((), dtype=F32, device=skip.device)
+            self._norm_coef[1] = torch.where(skip.reshape(()) != 0, torch.full_like(coef, -1.0), coef)
+            self._coef = self._norm_coef
         b1, b2 = self.betas
         gs = self.model.grad_state
         for g in self.param_groups:
@@ -164,6 +183,19 @@ class FusedAdamW:
                 elif zero_grad == "lazy" and gs[name] == "live":
                     gs[name] = "stale"
         self._coef = None
+
+    def uncount_step(self):
+        """A step that was dropped on the device (``step(skip=...)``) does not count towards the bias correction."""
+        self.step_count = max(0, self.step_count - 1)
+
+    def params_rewritten(self, base: bool = True, lora: bool = True):
+        """The bf16 working weights were overwritten from outside (``Model.load_state_dict``, ``broadcast_parameters``,
+        ``merge_lora_weights``): make them the master again.  With the split master the working copy IS the master's upper half,
+        so a stale ``lo`` would silently shift every weight by up to one bf16 ulp; re-seeding makes master == the new weights
+        (at fp32 where the loaded state dict was fp32).  Moments are kept."""
+        for g in self.param_groups:
+            if lora if g["name"] == "lora" else base:
+                self.set_master(g["name"], self._seed_master(g))
 
     def state_dict(self):
         return {"step": self.step_count,

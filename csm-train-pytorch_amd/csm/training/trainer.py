@@ -85,6 +85,8 @@ class CSMTrainer:
                                    "embeddings" if "embeddings" in n else "other"])
         self.logger.info(f"Training with {total:,} trainable parameters")
         self.grad_sync = GradSync.for_model(m) if GradSync.active() else None
+        if self.grad_sync is not None:
+            self.grad_sync.on_skip.append(lambda step: self.optimizer.uncount_step())
 
     def train_step(self, batch, accumulation_steps: int = 1, is_boundary: bool = True, max_grad_norm: float = 1.0):
         """One micro-batch: loss -> backward (-> on the boundary micro-batch: all-reduce, clip, AdamW, zero_grad)."""
@@ -103,7 +105,9 @@ class CSMTrainer:
                 self.grad_sync.finish()
             if max_grad_norm and max_grad_norm > 0:
                 self.optimizer.clip_grad_norm(max_grad_norm)
-            self.optimizer.step(zero_grad=True if os.environ.get("CSM_EAGER_ZERO_GRAD") else "lazy")
+            # (data parallel: a step whose text-row exchange ran over capacity is dropped on the device, on every rank)
+            self.optimizer.step(zero_grad=True if os.environ.get("CSM_EAGER_ZERO_GRAD") else "lazy",
+                                skip=self.grad_sync.skip_flag() if self.grad_sync is not None else None)
         return loss.detach(), details
 
     def train(self, train_dataset, val_dataset=None, batch_size: int = 2, accumulation_steps: int = 4, epochs: int = 5,
@@ -142,6 +146,8 @@ class CSMTrainer:
         avg_loss = float("nan")
         def save(epoch_, loss_, name="checkpoint"):
             # replicas are bit-identical: one writer (rank 0), the others wait so that nobody races ahead into a resume
+            if self.grad_sync is not None:
+                self.grad_sync.check_overflow(block=True)    # every dropped step is known (and un-counted) before state is written
             if rank0:
                 save_checkpoint(self.model, self.optimizer, epoch_, self.global_step, loss_, str(self.output_dir), name)
             if GradSync.active():
@@ -178,6 +184,9 @@ class CSMTrainer:
         if rank0:
             self.logger.info("Training completed")
         save(self.epoch, avg_loss, "final")
+        if self.grad_sync is not None and self.grad_sync.skipped_steps and rank0:
+            self.logger.warning(f"{len(self.grad_sync.skipped_steps)} optimiser step(s) were dropped (text-row exchange over capacity): "
+                                f"{self.grad_sync.skipped_steps}")
         return self.best_loss
 
     def _validate(self, val_loader) -> float:

@@ -17,7 +17,9 @@ extern "C" void csm_set_error(const char* fmt, ...) {
 
 extern "C" const char* csm_last_error(void) { return g_err; }
 
-extern "C" int csm_abi_version(void) { return 1; }
+// 2: csm_attn_bwd's scratch doubled (csm_attn_bwd_workspace_bytes), negative clip coefficient = skipped AdamW step
+extern "C" int csm_abi_version(void) { return 2; }
+extern "C" long long csm_attn_bwd_workspace_bytes(int B, int S, int H) { return 2LL * B * H * S * (long long)sizeof(float); }
 
 // 0 when a gfx950 device is visible to this process, otherwise an error code with text.
 extern "C" int csm_device_check(int device) {

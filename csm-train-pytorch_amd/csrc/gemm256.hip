@@ -12,6 +12,10 @@
 #include "gemm_common.h"
 
 int g_persistent = 1;     // csm_set_gemm256_persistent (gemm.hip)
+extern const char* g_last_gemm_kernel;   // csm_gemm_last_kernel (gemm.hip)
+#define CSM_KNAME256(TA, TB, f32) \
+    ((f32) ? (TA ? (TB ? "gemm256p_kernel<1, 1, float>" : "gemm256p_kernel<1, 0, float>") : (TB ? "gemm256p_kernel<0, 1, float>" : "gemm256p_kernel<0, 0, float>")) \
+           : (TA ? (TB ? "gemm256p_kernel<1, 1, unsigned short>" : "gemm256p_kernel<1, 0, unsigned short>") : (TB ? "gemm256p_kernel<0, 1, unsigned short>" : "gemm256p_kernel<0, 0, unsigned short>")))
 
 namespace {
 
@@ -360,6 +364,7 @@ int launch256(const Gemm256Args& g, int out_f32, int batch, hipStream_t stream) 
     dim3 grid(g_persistent && tiles > 256 ? 256 : tiles, 1, batch), block(512);
     const size_t lds = 10 * HALF;   // 160 KiB: the whole LDS of a CU
     static bool done[2] = {false, false};
+    g_last_gemm_kernel = CSM_KNAME256(TA, TB, out_f32);
     if (out_f32) {
         auto k = gemm256p_kernel<TA, TB, float>;
         if (!done[1]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[1] = true; }
@@ -437,6 +442,7 @@ int csm_gemm256_pair_launch(const void* dY, const void* W, void* dX, int M, int 
     static bool done = false;
     const size_t lds = 10 * HALF;
     if (!done) { (void)hipFuncSetAttribute((const void*)gemm256pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    g_last_gemm_kernel = "gemm256pair_kernel";
     hipLaunchKernelGGL(gemm256pair_kernel, dim3(p.na + p.nb), dim3(512), lds, stream, p);
     CSM_CHECK_LAUNCH("csm_gemm_bf16_dgrad_wgrad");
     return 0;
@@ -454,6 +460,7 @@ int csm_gemm256_two_wgrad_launch(const void* dY1, const void* X1, void* dW1, int
     static bool done = false;
     const size_t lds = 10 * HALF;
     if (!done) { (void)hipFuncSetAttribute((const void*)gemm256two_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    g_last_gemm_kernel = "gemm256two_tn_kernel";
     hipLaunchKernelGGL(gemm256two_tn_kernel, dim3(p.na + nb), dim3(512), lds, stream, p);
     CSM_CHECK_LAUNCH("csm_gemm_bf16_two_wgrad");
     return 0;

@@ -572,6 +572,16 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
     p = p - (lr / bc1) * (m / denom);
 }
 
+// A NEGATIVE clip coefficient on the device (norm_and_coef[1] < 0) means "this optimiser step does not happen": weights and
+// moments stay as they are, only the zero_grad side of the pass runs.  It is how a step whose gradients are known on the
+// device to be incomplete (data-parallel text-row exchange over capacity, training/dp.py) is dropped on every rank without
+// the host having to look at the flag before it launches the update.
+__device__ __forceinline__ void adamw_skipped(bf16_t* __restrict__ grad, long long nvec, int zero_grad) {
+    if (!zero_grad) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x)
+        *reinterpret_cast<U4*>(grad + i * 8) = (U4){0u, 0u, 0u, 0u};
+}
+
 // torch.optim.AdamW over one contiguous parameter range: fp32 master / m / v, bf16 gradient (times the device-side
 // clip coefficient), writes the bf16 working copy.  28 B/param of HBM traffic.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     // plain (default cache policy) 16-byte accesses: measured 5.6 TB/s; non-temporal loads/stores measured 4.5-5.0 TB/s here
     const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gmul;
     const long long nvec = n >> 3;
+    if (coef_ptr && coef_ptr[1] < 0.f) { adamw_skipped(grad, nvec, zero_grad); return; }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         float g[8];
         unpack8(*reinterpret_cast<const U4*>(grad + i * 8), g);
@@ -617,6 +628,7 @@ __global__ __launch_bounds__(256) void adamw_split_kernel(uint16_t* __restrict__
                                                           int zero_grad) {
     const float coef = (coef_ptr ? coef_ptr[1] : 1.f) * gmul;
     const long long nvec = n >> 3;
+    if (coef_ptr && coef_ptr[1] < 0.f) { adamw_skipped(grad, nvec, zero_grad); return; }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         float g[8];
         unpack8(*reinterpret_cast<const U4*>(grad + i * 8), g);

@@ -92,6 +92,10 @@ int csm_set_gemm_variant(int v);
 /* tuning switch: 1 (default) the 256x256 kernel runs one persistent workgroup per CU over its tile list (the next tile's first
  * loads are requested before the finished tile is stored); 0 one tile per workgroup */
 int csm_set_gemm256_persistent(int v);
+int csm_get_gemm256_persistent(void);
+/* name of the kernel (rocprofv3 spelling, without the argument list) the most recent csm_gemm_* call on this host thread's
+ * library instance launched - for benchmarks that attribute time to kernels; not thread-safe */
+const char* csm_gemm_last_kernel(void);
 
 /* ---- K2: torchtune RMSNorm (sa_norm / mlp_norm / norm; eps=1e-5 at model.py:22,39) -------------------------- */
 int csm_rmsnorm_fwd(const void* x, const void* scale, void* y, float* rstd, int M, int D, float eps, csm_stream_t stream);
@@ -120,8 +124,11 @@ int csm_rope(void* qkv, const float* table, const int* pos, long long M, int S, 
 int csm_set_attn_variant(int v); /* scheduling experiments: 0 = defaults; else bit fields (query tiles per wave, dK/dV key
                                   * tile and work order, heaviest-first order of the forward / dQ grid) - see attention.hip */
 int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, int HD, csm_stream_t stream);
+/* scratch of csm_attn_bwd / csm_attn_bwd_rope in BYTES (since ABI 2: 2 x [B][H][S] floats - the dQ pass leaves -delta and
+ * -lse*log2(e) per query there for the dK/dV pass; ABI 1 needed half).  Allocate at least this much for delta_ws. */
+long long csm_attn_bwd_workspace_bytes(int B, int S, int H);
 int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                 float* delta_ws /* scratch, 2 x [B][H][S] floats */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
+                 float* delta_ws /* scratch, csm_attn_bwd_workspace_bytes(B, S, H) */, int B, int S, int H, int KV, int HD, csm_stream_t stream);
 /* the same with the backward of csm_rope fused into the dQ / dK epilogues (table as for csm_rope, position = row index
  * inside the sequence): dqkv comes out as the gradient of the UN-rotated projection output, no separate inverse pass. */
 int csm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
@@ -165,6 +172,8 @@ int csm_reduce_sum_f32(const float* x, long long n, float scale, float* out, csm
 int csm_sumsq_blocks(void);
 int csm_sumsq_bf16(const void* g, long long n, float* partials /* [csm_sumsq_blocks()] */, csm_stream_t stream);
 int csm_clip_coef(const float* partials, int n_partials, float max_norm, float* norm_and_coef /* [2] */, csm_stream_t stream);
+/* norm_and_coef[1] < 0 on the device = skip this step: parameters and moments are left untouched, only zero_grad is honoured
+ * (how a data-parallel step with incomplete gradients is dropped on every rank without a host sync). */
 int csm_adamw_step(float* master, float* m, float* v, void* param, void* grad, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const float* norm_and_coef /* or NULL */,
                    float grad_mul, int zero_grad /* clear grad in the same pass */, csm_stream_t stream);

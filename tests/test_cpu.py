@@ -105,7 +105,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib.csm_abi_version() == 1
+    assert hip.lib.csm_abi_version() == 2
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -310,3 +310,29 @@ def test_gradsync_bucket_plan_for_model():
     # a backbone layer is one contiguous slice
     lay = [(s.offset, s.numel) for n, s in m._slots.items() if n.startswith("backbone.layers.1.")]
     assert len(GradSync._merge(lay)) == 1
+
+
+def test_bench_launches_and_verifies_its_own_ranks():
+    """``python bench.py --gpus N`` without a torchrun environment must start N ranks itself (children of a process that
+    has not touched the GPU), forward ONE JSON line that names N ranks, and fail loudly when the environment disagrees with
+    ``--gpus`` - the first 8-GPU driver run must not silently measure one GPU.  (``--dry-run``: rendezvous and collectives
+    over gloo on the CPU, no model.)"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl"]["world"] == 2 and out["steps"] == 3 and out["dry_run"] is True
+    # a launcher that started a different number of ranks than --gpus says: refuse
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr and not p.stdout.strip()
+    # and a single-process run asked for 1 GPU inside a 2-rank environment likewise
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr

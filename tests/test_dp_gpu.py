@@ -138,14 +138,18 @@ def _train_worker(rank, world, port, q, outdir, cap):
     ds = SyntheticCSMDataset(8, 24, cfg.text_vocab, cfg.audio_vocab, cfg.n_codebooks, seed=7)
     res = {}
     if cap:
-        try:
-            for step in range(3):
-                tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=50 + step + 10 * rank)
-                tr.train_step({"input_tokens": tokens, "input_masks": mask, "target_audio_tokens": targets}, 1, True, 1.0)
-                torch.cuda.synchronize()
-            res["raised"] = False
-        except RuntimeError as e:
-            res["raised"] = "CSM_DP_TEXT_ROWS_CAP" in str(e)
+        # NO host sync between the steps: the flag of step k is looked at by arm() of step k + 2 (or by close())
+        gs = tr.grad_sync
+        snaps = []
+        for step in range(8):
+            tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=50 + step + 10 * rank)
+            tr.train_step({"input_tokens": tokens, "input_masks": mask, "target_audio_tokens": targets}, 1, True, 1.0)
+            snaps.append(m.arena.clone())
+        gs.close()
+        torch.cuda.synchronize()
+        res.update(skipped=list(gs.skipped_steps), cap=gs.sparse["cap"], step_count=tr.optimizer.step_count,
+                   moved=[bool((snaps[i] != (snaps[i - 1] if i else snaps[0])).any()) for i in range(8)],
+                   state=m.arena.float().cpu().numpy(), persistent=__import__("csm.hip", fromlist=["lib"]).lib.csm_get_gemm256_persistent())
     else:
         tr.grad_sync.timing = True
         tr.train(ds, batch_size=2, accumulation_steps=1, epochs=1, save_every=1)
@@ -179,9 +183,11 @@ def test_two_rank_train_loop_one_writer(dev, tmp_path):
     assert len(res[0]["exposed"]) == 2 and all(x >= 0 for x in res[0]["exposed"])
 
 
-def test_text_row_exchange_overflow_is_reported(dev, tmp_path):
-    """More distinct text rows in a step than the exchange's fixed capacity: the device-side flag reaches the host one
-    step later and training stops with a clear message (no silent gradient loss, no per-step host sync)."""
+def test_text_row_exchange_overflow_drops_the_step_and_grows(dev, tmp_path):
+    """More distinct text rows in a step than the exchange's capacity (start value 1 row): the device-side flag - all-reduced,
+    so the same on both ranks - drops that optimiser step ON THE DEVICE (weights untouched), each step's flag reaches the
+    host in its own pinned slot two steps later WITHOUT any host sync in the loop, the capacity doubles until the step's
+    rows fit, training goes on, and the replicas stay bit-identical throughout."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30900 + os.getpid() % 1000
@@ -191,4 +197,84 @@ def test_text_row_exchange_overflow_is_reported(dev, tmp_path):
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(60)
-    assert res[0]["raised"] is True and res[1]["raised"] is True, res
+    a, b = res[0], res[1]
+    assert a["skipped"] == b["skipped"] and a["cap"] == b["cap"], (a["skipped"], b["skipped"], a["cap"], b["cap"])
+    assert a["skipped"][:2] == [0, 1], "steps 0 and 1 run before the host has seen the first flag (lag 2): both dropped"
+    assert len(a["skipped"]) < 8 and a["cap"] >= 2, "the capacity must have grown until a step went through"
+    # a dropped step leaves the weights exactly as they were; an applied one moves them
+    for i in range(1, 8):
+        assert a["moved"][i] == (i not in a["skipped"]), (i, a["moved"], a["skipped"])
+    assert a["step_count"] == 8 - len(a["skipped"]), "dropped steps are un-counted (AdamW bias correction)"
+    assert (a["state"] == b["state"]).all(), "replicas diverged"
+    assert a["persistent"] == 1, "GradSync.close() gives the process-global GEMM schedule switch back"
+
+
+def _rccl_worker(port, q):
+    """World size 1 over the REAL RCCL backend: no traffic leaves the GPU, but every RCCL-only code path of training/dp.py
+    executes on hardware - init_nccl with the high-priority stream option, all_gather_into_tensor in the text-row exchange,
+    the all-reduces on the side stream, the persistent-GEMM switch (forced on here through ``world_size``)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for p in (ROOT, os.path.join(ROOT, "csm-train-pytorch_amd")):
+        sys.path.insert(0, p)
+    from oracle import csm_oracle as O
+    from csm.hip import lib
+    from csm.models.model import Model, ModelArgs
+    from csm.training import dp
+    from csm.training.trainer import CSMTrainer
+    torch.cuda.set_device(0)
+    dp.init_nccl(0, 1, 0)
+    assert dist.get_backend() == "nccl"
+    cfg = O.tiny_cfg()
+
+    def build(seed):
+        m = Model(ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", cfg.text_vocab, cfg.audio_vocab, cfg.n_codebooks), device="cuda:0", seed=seed)
+        m.acoustic_mode = "all"
+        tr = CSMTrainer("", f"/tmp/csm_rccl_test_{port}_{seed}", device="cuda:0")
+        tr.logger.setLevel(40)
+        tr.model = m
+        return m, tr
+
+    # reference run: no GradSync at all
+    m0, tr0 = build(3)
+    tr0.prepare_optimizer()
+    assert tr0.grad_sync is None
+    # RCCL run: the same model and data, GradSync forced on over the 1-rank RCCL group
+    m1, tr1 = build(3)
+    real_active = dp.GradSync.active
+    dp.GradSync.active = staticmethod(lambda: True)
+    try:
+        tr1.prepare_optimizer()
+        gs = tr1.grad_sync
+        gs.world_size = 1
+        real_arm = gs.arm
+        gs.arm = lambda enabled=True: (real_arm(enabled), setattr(gs, "armed", bool(enabled)))   # armed although world == 1
+        for step in range(3):
+            tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=200 + step)
+            b = {"input_tokens": tokens, "input_masks": mask, "target_audio_tokens": targets}
+            l0, _ = tr0.train_step(b, 1, True, 1.0)
+            l1, _ = tr1.train_step(b, 1, True, 1.0)
+            assert float(l0) == float(l1), (step, float(l0), float(l1))
+        gs.close()
+        torch.cuda.synchronize()
+        q.put(dict(equal=bool(torch.equal(m0.arena, m1.arena)), log=list(gs.launch_log)[:12], skipped=list(gs.skipped_steps),
+                   backend=dist.get_backend(), persistent_after_close=lib.csm_get_gemm256_persistent()))
+    finally:
+        dp.GradSync.active = real_active
+    dist.destroy_process_group()
+
+
+def test_rccl_paths_execute_on_one_rank(dev):
+    """RCCL itself (not gloo) carries the DP step's collectives - with one rank, which is all a one-GPU box allows (RCCL
+    refuses two ranks on one device): the all-reduces and the all_gather_into_tensor of the text-row exchange are identities,
+    so three optimiser steps must leave exactly the weights of a run without GradSync."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(31900 + os.getpid() % 1000, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert res["backend"] == "nccl"
+    assert res["equal"], "a 1-rank RCCL DP step must be the identity on the gradients"
+    assert ("embeddings", "text-rows") in res["log"] and not res["skipped"], res
+    assert res["persistent_after_close"] == 1

@@ -44,6 +44,9 @@ if len(sys.argv) > 3:
             agg[kd][0] += rd; agg[kd][1] += wr; agg[kd][2] += n
     out = {kd: {"hbm_read_bytes_per_launch": v[0] / v[2], "hbm_write_bytes_per_launch": v[1] / v[2], "launches_profiled": v[2]}
            for kd, v in agg.items()}
+    # per kernel symbol (template arguments kept, argument list dropped): what bench.py's roofline.kernel names
+    out["_kernels"] = {k: {"hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n, "launches_profiled": n}
+                       for k, (rd, wr, n) in tot.items() if k.startswith("gemm")}
     out["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1 " \
                      "--no-cpu-baseline`; FETCH_SIZE x2 (gfx950 128-B request correction), KiB -> bytes"
     json.dump(out, open(sys.argv[3], "w"), indent=1)
