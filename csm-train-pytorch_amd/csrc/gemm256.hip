@@ -10,6 +10,7 @@
 // (the persistent one because loads, LDS-DMA and stores share one in-order vmcnt: the next tile's counted waits also wait
 // for the previous tile's stores) and were removed; they are in the history.
 #include "gemm_common.h"
+#include <type_traits>
 
 int g_persistent = 1;     // csm_set_gemm256_persistent (gemm.hip)
 extern const char* g_last_gemm_kernel;   // csm_gemm_last_kernel (gemm.hip)
@@ -101,16 +102,78 @@ __device__ __forceinline__ void dma_prepare(const bf16_t* __restrict__ P, int ld
         }
     }
 }
+// (round 3) The request itself is the BUFFER form of LDS-DMA: `buffer_load_dwordx4 v_off, s[rsrc], 0 offen lds` - a 128-bit
+// resource descriptor in scalar registers (rebuilt from the running scalar pointer: two scalar instructions) plus ONE 32-bit
+// per-lane offset.  The flat form (`global_load_lds_dwordx4 v[addr:addr+1]`) needed a 64-bit vector add per piece inside the K
+// loop and - worse - made hipcc keep eight 64-bit per-lane offsets and eight 64-bit running vector pointers alive: ~32 VGPRs
+// in a kernel that has none to spare (256 allocated, several values spilled to scratch and reloaded, each reload behind an
+// `s_waitcnt vmcnt(0)`, in the first K-tile of every output tile).
 __device__ __forceinline__ void issue_half_pre(const DmaSrc& d, int h, const char* b /* d.base[h] + K-tile * d.step, uniform */, char* lds) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (num_records = 2^32 - 1: the range check never fires; rows / columns past the matrix were clamped into it by dma_prepare)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b), 0, 0xffffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + d.off[h][i]),
-                                         (__attribute__((address_space(3))) void*)(lds + (wave * 2 + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (wave * 2 + i) * 1024), 16,
+                                                 (int)d.off[h][i], 0, 0, 0);
 }
 
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define BARRIER() __builtin_amdgcn_s_barrier()
+
+// compile-time loop: the index reaches inline-asm "i" operands as a constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 row_read_asm(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// Operand fragments whose EVERY LDS read is inline asm (round 3).  With plain loads for the K-contiguous image hipcc kept its
+// own lgkmcnt bookkeeping, and because it cannot see the asm transposed reads in between it fell back to `s_waitcnt lgkmcnt(0)`
+// in front of every MFMA group fed by plain loads - the prefetched pair was waited for in full in ph1 and ph3 - and put
+// `s_waitcnt vmcnt(0)` in front of the first plain LDS load after the prologue's LDS-DMA (possible alias), which also drained
+// K-tile 1's requests once per output tile.  Now nothing here is visible to that pass: the phase code counts its own waits.
+// Loads take a tile range [I0, I1) and a k-step (0, 1, or 2 = both) so that a phase can start its first MFMAs on the
+// fragments that arrive first.
+template <int T, int NT>
+struct AFrags {
+    bf16x8 row[NT][2];
+    FragT1 tr[NT][2];
+    template <int I0, int I1, int KS>
+    __device__ __forceinline__ void load(const char* img, int r0, int lane) {
+        if constexpr (T == 0) {
+            const int r = r0 + (lane & 15);
+            const unsigned a0 = (unsigned)(uintptr_t)img + r * 128 + (((lane >> 4) ^ (r & 7)) << 4);
+            const unsigned a1 = a0 ^ 64u;                      // k-step 1: 16-byte chunk index + 4, under the XOR swizzle
+            static_for<I0, I1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (KS != 1) row[i][0] = row_read_asm<i * 2048>(a0);
+                if constexpr (KS != 0) row[i][1] = row_read_asm<i * 2048>(a1);
+            });
+        } else {
+            const unsigned base = (unsigned)(uintptr_t)img + tr_lane_off(lane);
+            const int key = tr_lane_key(lane);
+            static_for<I0, I1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const unsigned a = base + ((((r0 >> 4) + i) ^ key) << 5);
+                if constexpr (KS != 1) tr[i][0] = load_frag_tr<0>(a);
+                if constexpr (KS != 0) tr[i][1] = load_frag_tr<1>(a);
+            });
+        }
+    }
+    // LDS read instructions of load<I0, I1, KS>
+    static constexpr int reads(int tiles, int ksteps) { return tiles * ksteps * (T == 0 ? 1 : 2); }
+    __device__ __forceinline__ bf16x8 get(int i, int ks) const {
+        if constexpr (T == 0) return row[i][ks];
+        else return cat4(tr[i][ks].lo, tr[i][ks].hi);
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // A K-tile is four phases.  A phase multiplies ONE pair of A m-tiles (32 rows) by all four B n-tiles of the wave
@@ -232,12 +295,19 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     } else { WAIT_VM(0); }
     BARRIER();
 
-    Frags<TB, 4> fb;
-    Frags<TA, 2> fa0, fa1;
-    fa0.load(slotA(0, a_half), 0, lane);
-    if (ABL_L) { fb.load(slotB(0, b_half), b_off, lane); fa1.load(slotA(0, a_half), 32, lane); }
+    AFrags<TB, 4> fb;
+    AFrags<TA, 2> fa0, fa1;
+    if (!ABL_L) { fb.template load<0, 2, 2>(slotB(0, b_half), b_off, lane); fa0.template load<0, 2, 2>(slotA(0, a_half), 0, lane); }
+    if (ABL_L) { fb.template load<0, 4, 2>(slotB(0, b_half), b_off, lane); fa1.template load<0, 2, 2>(slotA(0, a_half), 32, lane); }
     int b3 = 0;   // t % 3
-#define WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"((n) > 15 ? 15 : (n)) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    constexpr int RB = AFrags<TB, 4>::reads(2, 1);            // B reads of two n-tiles, one k-step
+    // MFMAs of A pair FA (rows MI, MI + 1 of the wave's 8 m-tiles) x n-tiles [J0, J1) at k-step KS
+#define MFMA_GROUP(FA, MI, J0, J1, KS)                                                                                 \
+    if (!ABL_M) {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                     \
+        _Pragma("unroll") for (int j = J0; j < J1; ++j)                                                               \
+            acc[MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, KS), FA.get(i, KS), acc[MI + i][j], 0, 0, 0); }
 #define MFMA_PAIR(FA, MI)                                                                                              \
     if (!ABL_M) { if (!NO_PRIO) __builtin_amdgcn_s_setprio(1);                                                                                     \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
@@ -246,27 +316,44 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
                 acc[MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.get(j, ks), FA.get(i, ks), acc[MI + i][j], 0, 0, 0); \
     if (!NO_PRIO) __builtin_amdgcn_s_setprio(0); }
 
+    // (no unrolling AND no peeling: hipcc peeled the first K-tile - the `t == 0` conditions - and hoisted that copy's LDS
+    // addresses out of the tile loop, where they were spilled to scratch: a dozen reloads, each behind `s_waitcnt vmcnt(0)`,
+    // in the first K-tile of every output tile)
+#pragma clang loop unroll(disable)
     for (int t = 0; t < nt; ++t) {
         const int b = t & 1;
         const int b3n = b3 == 0 ? 2 : b3 - 1;            // (t + 2) % 3
         const char* la = slotA(b, a_half);
         const char* lb = slotB(b3, b_half);
-        // ---- ph1: pair 0 (set 0)   | reads B(t) (exposed) + prefetch pair 1
+        // ---- ph1: pair 0 (set 0).  B fragments: n-tiles 0, 1 were requested in ph4 of the previous K-tile (below) and have
+        // had its last 8 MFMAs to arrive; n-tiles 2, 3 are requested here and arrive under this phase's first 8 MFMAs.
         if (!EARLY && t + 1 < nt && !(t == 0 && a1_pre)) issueA(1, -1, t + 1, b ^ 1);
         if (EARLYB && t + 2 < nt) issueB(0, 0, t + 2, b3n);
-        if (!ABL_L) { fb.load(lb, b_off, lane);
-        fa1.load(la, 32, lane); }
-        WAIT_LGKM(NRA);
-        MFMA_PAIR(fa0, 0)
+        if (!ABL_L) {
+            fb.template load<2, 4, 0>(lb, b_off, lane);
+            fb.template load<2, 4, 1>(lb, b_off, lane);
+            WAIT_LGKM(2 * RB);                                  // ph4's requests (B n-tiles 0, 1 and A pair 0) are in
+            if (!NO_PRIO) __builtin_amdgcn_s_setprio(1);
+            MFMA_GROUP(fa0, 0, 0, 2, 0)
+            MFMA_GROUP(fa0, 0, 0, 2, 1)
+            fa1.template load<0, 2, 2>(la, 32, lane);
+            WAIT_LGKM(RB + NRA);
+            MFMA_GROUP(fa0, 0, 2, 4, 0)
+            WAIT_LGKM(NRA);
+            MFMA_GROUP(fa0, 0, 2, 4, 1)
+            if (!NO_PRIO) __builtin_amdgcn_s_setprio(0);
+        } else {
+            MFMA_PAIR(fa0, 0)
+        }
         // ---- ph2: pair 1 (set 1)   | prefetch pair 2 -> set 0
         if (t + 2 < nt) issueB(EARLYB ? 1 : 0, 0, t + 2, b3n);
-        if (!ABL_L) fa0.load(la, 64, lane);
+        if (!ABL_L) fa0.template load<0, 2, 2>(la, 64, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa1, 2)
         // (no barrier: the B slots were released by ph1's barrier, nothing new has to be visible yet)
         // ---- ph3: pair 2 (set 0)   | prefetch pair 3 -> set 1
         if (!EARLYB && t + 2 < nt) issueB(1, 0, t + 2, b3n);
-        if (!ABL_L) fa1.load(la, 96, lane);
+        if (!ABL_L) fa1.template load<0, 2, 2>(la, 96, lane);
         WAIT_LGKM(NRA);
         MFMA_PAIR(fa0, 4)
         WAIT_LGKM(0);                                           // pair-3 reads done: the A slots of this buffer are dead
@@ -274,16 +361,32 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         // was requested in full before them, and only the two B halves of K-tile 2 - 4 instructions - after them)
         if (t + 2 < nt) { if (t == 0 && pend > 0) { const int w = min(63, 4 + pend); WAIT_VM_DYN(w); } else { WAIT_VM(4); } } else { WAIT_VM(0); }
         if (!ABL_B) BARRIER();
-        // ---- ph4: pair 3 (set 1)   | prefetch pair 0 of tile t+1 -> set 0
+        // ---- ph4: pair 3 (set 1)   | after its first 8 MFMAs (n-tiles 0, 1, both k-steps) those B registers are free: the B
+        // fragments of n-tiles 0, 1 of K-tile t+1 (published by the barrier above) and A pair 0 of t+1 are requested under
+        // the other 8 MFMAs - ph1(t+1) then starts on operands that are already there instead of waiting for its first read
         if (t + 2 < nt) { issueA(0, 0, t + 2, b); if (EARLY) issueA(1, 0, t + 2, b); }
-        if (!ABL_L && t + 1 < nt) fa0.load(slotA(b ^ 1, a_half), 0, lane);
-        WAIT_LGKM(NRA);
-        MFMA_PAIR(fa1, 6)
+        if (!ABL_L) {
+            if (!NO_PRIO) __builtin_amdgcn_s_setprio(1);
+            MFMA_GROUP(fa1, 6, 0, 2, 0)
+            MFMA_GROUP(fa1, 6, 0, 2, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nt) {
+                fb.template load<0, 2, 2>(slotB(b3 == 2 ? 0 : b3 + 1, b_half), b_off, lane);
+                fa0.template load<0, 2, 2>(slotA(b ^ 1, a_half), 0, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_GROUP(fa1, 6, 2, 4, 0)
+            MFMA_GROUP(fa1, 6, 2, 4, 1)
+            if (!NO_PRIO) __builtin_amdgcn_s_setprio(0);
+        } else {
+            MFMA_PAIR(fa1, 6)
+        }
         // (no barrier: ph1(t+1) only touches slots ph3's barrier has already released / published)
         b3 = b3 == 2 ? 0 : b3 + 1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) { pa[h] += srcA.step; pb[h] += srcB.step; }
     }
+#undef MFMA_GROUP
 #undef MFMA_PAIR
 
     if (g.kx) k_extend<8>(g.xA, g.xB, g.kx, g.M, g.N, m0 + wr * 128, n0 + wc * 64, lane, acc);

@@ -207,6 +207,26 @@ struct Frags {
 };
 
 // ---- epilogue ------------------------------------------------------------------------------------------------
+// Result stores of the fast epilogue paths, as inline asm: a store hipcc knows about is a pending vector-memory event at
+// the back-edge of the persistent 256x256 kernel's tile loop, and with LDS-DMA requests pending beside it (two event kinds
+// on one in-order counter) the compiler's wait insertion degrades to `s_waitcnt vmcnt(0)` in front of the next tile's first
+// fragment read - every tile waited for the previous tile's stores to be acknowledged, which is exactly what requesting the
+// next tile's operands before the stores was meant to avoid (round 3, found in the ISA).  Unknown to the compiler, the
+// stores only make its own counted waits for epilogue LOADS stricter (counts are upper bounds of what may stay in flight).
+// (`s_nop 0`: a store of more than 8 bytes needs one wait state before its data registers may be overwritten.)
+__device__ __forceinline__ void store16_asm(void* p, const U4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store8_asm(void* p, const uint2& v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store4_asm(void* p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store2_asm(void* p, uint32_t v /* low 16 bits */) {
+    asm volatile("global_store_short %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
 // One 16x16 accumulator: the lane owns C[m][n .. n+3].  mode 0: C = alpha*acc (+R).  mode 1 (SwiGLU forward, bf16 out,
 // gate/up interleaved along n): additionally aux_out[m][n/2 .. n/2+1] = silu(gate) * up.  mode 2 (SwiGLU backward,
 // GEMM N = F): acc is d(act)[m][n..n+3]; reads gate/up from aux_in[m][2n .. 2n+7] and writes d(gate),d(up)
@@ -252,7 +272,7 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
                 o[2 * i] = v[i] * up * sg * (1.f + gt * (1.f - sg));
                 o[2 * i + 1] = v[i] * gt * sg;
             }
-            *reinterpret_cast<U4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + 2 * n) = pack8(o);
+            store16_asm(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + 2 * n, pack8(o));
         }
         return;
     }
@@ -265,21 +285,22 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
         if (e.mode == EPI_ROPE) epi_rope<2>(e, m, n, v);
         if constexpr (sizeof(OutT) == 2) {
             uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;
+            store8_asm(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n, o);
             if (e.mode == EPI_SWIGLU_FWD) {
                 const float a0 = silu(v[0]) * v[1];
                 const float a1 = silu(v[2]) * v[3];
-                *reinterpret_cast<uint32_t*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = pack2bf(a0, a1);
+                store4_asm(e.aux_out + (size_t)m * e.ld_aux + (n >> 1), pack2bf(a0, a1));
             }
         } else {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.C) + (size_t)m * e.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            store16_asm(reinterpret_cast<float*>(e.C) + (size_t)m * e.ldc + n,
+                        (U4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
         }
     } else {
         for (int k = 0; k < 4 && n + k < e.N; ++k) {
             float x = v[k];
             if (e.R) x += bf2f(e.R[(size_t)m * e.ldr + n + k]);
-            if constexpr (sizeof(OutT) == 2) reinterpret_cast<bf16_t*>(e.C)[(size_t)m * e.ldc + n + k] = f2bf(x);
-            else reinterpret_cast<float*>(e.C)[(size_t)m * e.ldc + n + k] = x;
+            if constexpr (sizeof(OutT) == 2) store2_asm(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n + k, f2bf(x));
+            else store4_asm(reinterpret_cast<float*>(e.C) + (size_t)m * e.ldc + n + k, __float_as_uint(x));
         }
     }
 }
@@ -323,7 +344,7 @@ __device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int n
                     o[2 * k] = v * up * sg * (1.f + gt * (1.f - sg));
                     o[2 * k + 1] = v * gt * sg;
                 }
-                if (m < e.M && n < e.N) *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + 2 * n) = pack8(o);
+                if (m < e.M && n < e.N) store16_asm(C + (size_t)m * e.ldc + 2 * n, pack8(o));
             }
     }
 }
@@ -364,13 +385,13 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
         for (int k = 0; k < 8; ++k) v[k] += rr[k];
     }
     if (e.mode == EPI_ROPE) epi_rope<4>(e, m, n, v);
-    *reinterpret_cast<U4*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = pack8(v);
+    store16_asm(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n, pack8(v));
     if (e.mode == EPI_SWIGLU_FWD) {   // v = g0,u0,g1,u1,g2,u2,g3,u3 (gate / up interleaved along N): four activations, one 8-byte store
         float a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = silu(v[2 * k]) * v[2 * k + 1];
         uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
-        *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
+        store8_asm(e.aux_out + (size_t)m * e.ld_aux + (n >> 1), w);
     }
 }
 
@@ -451,7 +472,7 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                         const float a2 = v[4 * h + 2] * q[h].z - v[4 * h + 3] * q[h].w, a3 = v[4 * h + 3] * q[h].z + v[4 * h + 2] * q[h].w;
                         v[4 * h] = a0; v[4 * h + 1] = a1; v[4 * h + 2] = a2; v[4 * h + 3] = a3;
                     }
-                    if (m < e.M) *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + n) = pack8(v);
+                    if (m < e.M) store16_asm(C + (size_t)m * e.ldc + n, pack8(v));
                 }
             }
             return 6 * NI;        // 4 NI table loads + 2 NI stores
@@ -480,13 +501,13 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                 }
                 const int n = nl + 32 * jp;
                 if (m < e.M) {
-                    *reinterpret_cast<U4*>(C + (size_t)m * e.ldc + n) = pack8(v);
+                    store16_asm(C + (size_t)m * e.ldc + n, pack8(v));
                     if (e.mode == EPI_SWIGLU_FWD) {
                         float a[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) a[k] = silu(v[2 * k]) * v[2 * k + 1];
                         uint2 w; w.x = pack2bf(a[0], a[1]); w.y = pack2bf(a[2], a[3]);
-                        *reinterpret_cast<uint2*>(e.aux_out + (size_t)m * e.ld_aux + (n >> 1)) = w;
+                        store8_asm(e.aux_out + (size_t)m * e.ld_aux + (n >> 1), w);
                     }
                 }
             }
