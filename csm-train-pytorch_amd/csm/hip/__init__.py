@@ -38,6 +38,7 @@ _SIGS = {
     "csm_set_gemm_variant": ([_i], _i),
     "csm_set_gemm256_persistent": ([_i], _i),
     "csm_get_gemm256_persistent": ([], _i),
+    "csm_set_gemm_tuning": ([_i, _i], _i),
     "csm_gemm_last_kernel": ([], C.c_char_p),
     "csm_attn_bwd_workspace_bytes": ([_i, _i, _i], _ll),
     "csm_rmsnorm_fwd": ([_p, _p, _p, _p, _i, _i, _f, _p], _i),
@@ -93,6 +94,8 @@ for _name, (_args, _res) in _SIGS.items():
 EXPORTS = tuple(_SIGS)
 if os.environ.get("CSM_GEMM256_PERSISTENT") == "0":     # kernel A/B only (tools/probes)
     lib.csm_set_gemm256_persistent(0)
+if os.environ.get("CSM_GEMM_TOUCH") == "0":             # kernel A/B only (tools/probes)
+    lib.csm_set_gemm_tuning(0, 0)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -254,6 +254,14 @@ extern "C" int csm_set_gemm256_persistent(int v) { g_persistent = v ? 1 : 0; ret
 extern "C" int csm_get_gemm256_persistent(void) { return g_persistent; }
 extern "C" const char* csm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
+// tuning switches of the 256x256 kernel for A/B runs: key 0 = epilogue-read prefetch (default 1)
+extern int g_gemm_touch;
+extern "C" int csm_set_gemm_tuning(int key, int value) {
+    CSM_REQUIRE(key == 0, "csm_set_gemm_tuning: unknown key %d", key);
+    g_gemm_touch = value ? 1 : 0;
+    return 0;
+}
+
 extern "C" int csm_set_gemm_variant(int v) {
     CSM_REQUIRE(v >= 0 && v <= 3, "csm_set_gemm_variant: %d is not one of 0..3", v);
     g_gemm_variant = v;

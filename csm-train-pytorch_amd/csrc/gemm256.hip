@@ -13,6 +13,7 @@
 #include <type_traits>
 
 int g_persistent = 1;     // csm_set_gemm256_persistent (gemm.hip)
+int g_gemm_touch = 1;     // csm_set_gemm_tuning(0, v): epilogue-read prefetch in the 256x256 kernel
 extern const char* g_last_gemm_kernel;   // csm_gemm_last_kernel (gemm.hip)
 #define CSM_KNAME256(TA, TB, f32) \
     ((f32) ? (TA ? (TB ? "gemm256p_kernel<1, 1, float>" : "gemm256p_kernel<1, 0, float>") : (TB ? "gemm256p_kernel<0, 1, float>" : "gemm256p_kernel<0, 0, float>")) \
@@ -32,6 +33,7 @@ struct Gemm256Args {
     int epi_mode; const bf16_t* aux_in; bf16_t* aux_out; int ld_aux;
     int epi_p0, epi_p1;
     const bf16_t* xA; const bf16_t* xB; int kx;      // K-extension operands (gemm_common.h: k_extend)
+    int touch;                                       // epilogue-read prefetch on (csm_set_gemm_tuning(0, v))
 };
 
 // one 16-KiB half-tile by LDS-DMA: 16 pieces of 1 KiB over 8 waves
@@ -277,6 +279,39 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     };
     prologue(EARLY);
     int pend = 0;                               // memory operations of the previous tile's epilogue issued after the prologue
+    // ---- epilogue-read prefetch ("touches").  The fused epilogues that READ a tile-sized operand - gate/up of the
+    // SwiGLU-backward epilogue (256 KiB per tile), a bf16 residual (128 KiB) - used to start those reads when the main loop
+    // was over, on every CU at the same moment, at HBM latency and into a saturated HBM.  Now each lane touches one dword of
+    // each 64-byte piece of the tile's operand during the last K-tiles (one `global_load_dword` per wave and K-tile, in ph4):
+    // the lines travel HBM -> Infinity Cache / L2 under the main loop and the epilogue's loads hit cache.  The loaded value
+    // is never used; its register stays reserved until the loop's final `vmcnt(0)`.
+    const char* tch_base = nullptr;
+    long long tch_ld = 0, tch_col0 = 0, tch_row_bytes = 0;
+    int tch_n = 0, tch_cl2 = 0;
+    if constexpr (sizeof(OutT) == 2) {
+        if (g.touch && nt >= 16) {
+            if (g.epi_mode == EPI_SWIGLU_BWD) {
+                tch_base = reinterpret_cast<const char*>(g.aux_in); tch_ld = (long long)g.ld_aux * 2; tch_n = 8; tch_cl2 = 4;
+                tch_row_bytes = (long long)g.N * 4;
+            } else if (g.R) {
+                tch_base = reinterpret_cast<const char*>(g.R + (size_t)bz * g.sR); tch_ld = (long long)g.ldr * 2; tch_n = 4; tch_cl2 = 3;
+                tch_row_bytes = (long long)g.N * 2;
+            }
+        }
+    }
+    // spread over the whole main loop (all of them within its last third made the loop's own operand fetches queue behind 67 MB
+    // of prefetch: same total time); the last one is at least two K-tiles old when the loop's final wait drains the queue
+    const int tch_stride = tch_n ? max(1, (nt - 4) / tch_n) : 1;
+    int tch_next = 1, tch_q = 0;                // K-tile of the next touch, touches done (per output tile)
+    bool tch_prev = false;                      // a touch went out in this K-tile's ph1
+    unsigned junk = 0;
+    auto touch = [&](int q) {
+        const int idx = q * 512 + (int)threadIdx.x;
+        const int row = idx >> tch_cl2, ch = idx & ((1 << tch_cl2) - 1);
+        const long long colb = min(tch_col0 + ch * 64, tch_row_bytes - 4);
+        const char* ptr = tch_base + (long long)min(m0 + row, g.M - 1) * tch_ld + colb;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(ptr) : "memory");
+    };
     // Whether K-tile 1 is COMPLETE in the prologue (8 instructions) or lacks A1 (6; then ph1(0) requests it).  The counted
     // waits past the previous tile's epilogue (``pend``) are only sound when everything the wait is for was requested BEFORE
     // that epilogue: A1(1) requested in ph1(0) is younger than the stores, and `vmcnt(4 + pend)` at ph3(0) would not wait for
@@ -284,6 +319,8 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     // tiles of a workgroup always take the complete prologue.
     bool a1_pre = EARLY;
   for (;;) {
+    tch_col0 = (long long)n0 * (tch_cl2 == 4 ? 4 : 2);          // gate/up: columns 2 n0 .. of 2-byte elements; residual: n0 ..
+    tch_next = 1; tch_q = 0; tch_prev = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -328,6 +365,10 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         // ---- ph1: pair 0 (set 0).  B fragments: n-tiles 0, 1 were requested in ph4 of the previous K-tile (below) and have
         // had its last 8 MFMAs to arrive; n-tiles 2, 3 are requested here and arrive under this phase's first 8 MFMAs.
         if (!EARLY && t + 1 < nt && !(t == 0 && a1_pre)) issueA(1, -1, t + 1, b ^ 1);
+        // (the touch goes out AFTER every A request of tile t+2 - for the non-EARLY layouts A1 is requested just above - so that the
+        // wait at the end of ph3, which is for those A pieces, can leave it in flight: vmcnt(5) instead of vmcnt(4))
+        tch_prev = false;
+        if (tch_q < tch_n && t == tch_next && t + 3 < nt) { touch(tch_q); ++tch_q; tch_next += tch_stride; tch_prev = true; }
         if (EARLYB && t + 2 < nt) issueB(0, 0, t + 2, b3n);
         if (!ABL_L) {
             fb.template load<2, 4, 0>(lb, b_off, lane);
@@ -359,7 +400,12 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
         WAIT_LGKM(0);                                           // pair-3 reads done: the A slots of this buffer are dead
         // tile t+1 has landed (for t = 0 of a later tile of this workgroup, counted past the previous tile's stores: K-tile 1
         // was requested in full before them, and only the two B halves of K-tile 2 - 4 instructions - after them)
-        if (t + 2 < nt) { if (t == 0 && pend > 0) { const int w = min(63, 4 + pend); WAIT_VM_DYN(w); } else { WAIT_VM(4); } } else { WAIT_VM(0); }
+        // (a touch issued in this K-tile's ph1 is younger than the A pieces this wait is for: it stays in flight too)
+        if (t + 2 < nt) {
+            if (t == 0 && pend > 0) { const int w = min(63, 4 + pend); WAIT_VM_DYN(w); }
+            else if (tch_prev) { WAIT_VM(5); }
+            else { WAIT_VM(4); }
+        } else { WAIT_VM(0); }
         if (!ABL_B) BARRIER();
         // ---- ph4: pair 3 (set 1)   | after its first 8 MFMAs (n-tiles 0, 1, both k-steps) those B registers are free: the B
         // fragments of n-tiles 0, 1 of K-tile t+1 (published by the barrier above) and A pair 0 of t+1 are requested under
@@ -388,6 +434,7 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     }
 #undef MFMA_GROUP
 #undef MFMA_PAIR
+    asm volatile("" ::"v"(junk));               // (the touches' destination register was reserved up to here)
 
     if (g.kx) k_extend<8>(g.xA, g.xB, g.kx, g.M, g.N, m0 + wr * 128, n0 + wc * 64, lane, acc);
 
@@ -502,7 +549,7 @@ int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int
                        hipStream_t stream, int epi_p0, int epi_p1, const void* xA, const void* xB, int kx) {
     Gemm256Args g;
     g.epi_p0 = epi_p0; g.epi_p1 = epi_p1;
-    g.xA = (const bf16_t*)xA; g.xB = (const bf16_t*)xB; g.kx = kx;
+    g.xA = (const bf16_t*)xA; g.xB = (const bf16_t*)xB; g.kx = kx; g.touch = g_gemm_touch;
     g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
@@ -519,7 +566,7 @@ static void fill256(Gemm256Args& g, const void* A, const void* B, void* C, const
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.R = (const bf16_t*)R;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
     g.sA = g.sB = g.sC = g.sR = 0; g.alpha = alpha;
-    g.xA = g.xB = nullptr; g.kx = 0;
+    g.xA = g.xB = nullptr; g.kx = 0; g.touch = g_gemm_touch;
     g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
     g.epi_mode = epi_mode; g.aux_in = (const bf16_t*)aux_in; g.aux_out = (bf16_t*)aux_out; g.ld_aux = ld_aux;
     g.epi_p0 = g.epi_p1 = 0;

@@ -310,6 +310,9 @@ __device__ __forceinline__ void epi_store(const Epi& e, bool vec_ok, int m, int 
 // stored - issued one by one between the stores they would sit behind every store's address check and the epilogue
 // would pay one full memory latency per accumulator.  The loads of the next row pair are issued before this pair's
 // arithmetic and stores (two register buffers), so the memory system always has this wave's reads queued.
+#ifndef CSM_ABLATE_EPI
+#define CSM_ABLATE_EPI 0        // tools/probes: 1 = no gate/up loads, 2 = no stores, 4 = no sigmoid arithmetic
+#endif
 template <int NI, int NJ>
 __device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int nb, int lane, const f32x4 (&acc)[NI][NJ]) {
     const int g = lane >> 4;
@@ -322,7 +325,8 @@ __device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int n
             for (int j = 0; j < NJ; ++j) {
                 // (lanes outside the matrix read a clamped, valid address and never store: no branch between the loads)
                 const int m = min(mb + 16 * (i + ii) + (lane & 15), e.M - 1), n = min(nb + 16 * j + 4 * g, e.N - 4);
-                dst[ii][j] = *reinterpret_cast<const U4*>(e.aux_in + (size_t)m * e.ld_aux + 2 * n);
+                if (CSM_ABLATE_EPI & 1) dst[ii][j] = (U4){0x3f803f80u + (unsigned)m, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + (unsigned)n};
+                else dst[ii][j] = *reinterpret_cast<const U4*>(e.aux_in + (size_t)m * e.ld_aux + 2 * n);
             }
     };
     fetch(0, gu[0]);
@@ -340,11 +344,11 @@ __device__ __forceinline__ void epi_swiglu_bwd_block(const Epi& e, int mb, int n
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = acc[i + ii][j][k] * e.alpha, gt = gv[2 * k], up = gv[2 * k + 1];
-                    const float sg = fast_sigmoid(gt);
+                    const float sg = (CSM_ABLATE_EPI & 4) ? gt : fast_sigmoid(gt);
                     o[2 * k] = v * up * sg * (1.f + gt * (1.f - sg));
                     o[2 * k + 1] = v * gt * sg;
                 }
-                if (m < e.M && n < e.N) store16_asm(C + (size_t)m * e.ldc + 2 * n, pack8(o));
+                if ((CSM_ABLATE_EPI & 2) ? (m < 0 && o[0] == 12345.f) : (m < e.M && n < e.N)) store16_asm(C + (size_t)m * e.ldc + 2 * n, pack8(o));
             }
     }
 }
