@@ -710,6 +710,11 @@ class _DecodeStack:
         self.pos = torch.zeros(B, dtype=torch.int32, device=dev)
         self.xn, self.qkv, self.o, self.h, self.hn = z(B, d), z(B, c.qkv_dim), z(B, H * hd), z(B, d), z(B, d)
         self.gu, self.act, self.xa, self.xb, self.xf = z(B, 2 * F), z(B, F), z(B, d), z(B, d), z(B, d)
+        # four launches per layer instead of five where the cache is short (csm_gemv_attn_bf16: S_max <= 64, head_dim 128).  Only
+        # for one utterance: every workgroup of the fused launch recomputes the attention of all (row, head) pairs, which costs
+        # more than the launch it saves from two rows on (measured: 149 vs 147 frames/s at B = 1, 331 vs 402 aggregate at B = 4)
+        import os
+        self.fuse_attn = B == 1 and s_max <= 64 and hd == 128 and os.environ.get("CSM_DECODE_FUSE_ATTN", "1") == "1"
 
     def fill_from(self, acts, B, S):
         """Copy the post-RoPE K / V rows of a prefilled prompt into the caches."""
@@ -737,11 +742,16 @@ class _DecodeStack:
         table = st.m.rope_table(st.prefix)
         cur, nxt = x, self.xa
         for i in range(c.num_layers):
-            # five launches per layer: the norms ride in the prologue of the following matrix-vector product, RoPE and
-            # the cache append inside the attention kernel, SwiGLU in the epilogue of the w13 product
+            # five launches per layer (four in the depth decoder): the norms ride in the prologue of the following matrix-vector
+            # product, RoPE and the cache append inside the attention kernel, SwiGLU in the epilogue of the w13 product
             ops.gemv_ex(cur, st.w(f"layers.{i}.attn.qkv"), self.qkv, norm_scale=st.w(f"layers.{i}.sa_norm.scale"), eps=c.norm_eps)
-            ops.attn_decode_rope(self.qkv, self.k[i], self.v[i], self.o, self.pos, table, H, KV, hd)
-            ops.gemv(self.o, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, residual=cur)
+            if self.fuse_attn:
+                # (depth decoder: <= 32 cached positions - the attention rides in the prologue of the output projection)
+                ops.gemv_attn(self.qkv, self.k[i], self.v[i], self.pos, table, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, cur,
+                              H, KV, hd)
+            else:
+                ops.attn_decode_rope(self.qkv, self.k[i], self.v[i], self.o, self.pos, table, H, KV, hd)
+                ops.gemv(self.o, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, residual=cur)
             ops.gemv_ex(self.h, st.w(f"layers.{i}.mlp.w13"), self.act, norm_scale=st.w(f"layers.{i}.mlp_norm.scale"), eps=c.norm_eps,
                         swiglu=True)
             ops.gemv(self.act, st.w(f"layers.{i}.mlp.w2.weight"), nxt, residual=self.h)

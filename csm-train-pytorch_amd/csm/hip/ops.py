@@ -385,6 +385,18 @@ def attn_decode_rope(qkv, kcache, vcache, out, pos_i32, table, H, KV, HD):
     return out
 
 
+def gemv_attn(qkv, kcache, vcache, pos_i32, table, W, y, residual, H, KV, HD):
+    """A depth-decoder layer's rope + append + attention + output projection (+ residual) in one launch (S_max <= 64,
+    HD = 128); bit-identical to ``attn_decode_rope`` followed by ``gemv``."""
+    B, _, S_max, _ = kcache.shape
+    N = W.shape[0]
+    assert table.dtype == torch.float32 and table.is_contiguous() and W.shape[1] == H * HD and W.stride(1) == 1 and y.shape == (B, N)
+    check(lib.csm_gemv_attn_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), pos_i32.data_ptr(), table.data_ptr(),
+                                 W.data_ptr(), y.data_ptr(), _ptr(residual), B, N, H, KV, HD, S_max, qkv.stride(0), W.stride(0),
+                                 y.stride(0), _stream()), "csm_gemv_attn_bf16")
+    return y
+
+
 def gemv_t(x, W, y):
     """y[B,N] = x[B,K] W[K,N], B <= 4."""
     B, K = x.shape

@@ -38,7 +38,9 @@ __device__ __forceinline__ ValIdx block_arg(ValIdx x, ValIdx* red) {
 // counts "keys >= trial" with wave ballots + scalar popcounts (no cross-lane shuffles: __shfl_xor is an LDS-crossbar
 // ds_bpermute, six of them per reduction were most of the first version's 26 us) and ONE barrier (the per-wave counts
 // alternate between two LDS slots).  A generated frame draws 32 codes one after the other, so this kernel's latency is
-// paid 32 times per 80 ms of audio.
+// paid 32 times per 80 ms of audio.  (Round 3 tried four bits per round - 8 barriers instead of 32, 15 trial values each:
+// 40 us instead of 20.  The ballots, not the barriers, are the cost: each is a vector compare whose scalar result a scalar
+// popcount then waits for, ~70 ns a piece, and the wide round needs 135 of them.)
 constexpr int SMP_PER_THREAD = 16;
 template <int NPT>
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, const float* __restrict__ q,
@@ -65,9 +67,14 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     uint32_t prefix = 0u;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t trial = prefix | (1u << bit);
+        // per-lane count first (vector compares and adds), then ONE ballot per bit of that count: 4-5 ballots a round instead
+        // of one per key (round 3: a ballot's scalar result feeds a scalar popcount that has to wait for it, ~70 ns each)
+        int cl = 0;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) cl += key[j] >= trial ? 1 : 0;
         int c = 0;                                       // wave-uniform: every ballot is a scalar mask
 #pragma unroll
-        for (int j = 0; j < NPT; ++j) c += __popcll(__ballot(key[j] >= trial));
+        for (int bb = 0; (1 << bb) <= NPT; ++bb) c += __popcll(__ballot((cl >> bb) & 1)) << bb;
         if ((threadIdx.x & 63) == 0) cnt_s[bit & 1][wave] = c;
         __syncthreads();
         if (cnt_s[bit & 1][0] + cnt_s[bit & 1][1] + cnt_s[bit & 1][2] + cnt_s[bit & 1][3] >= topk) prefix = trial;
@@ -423,6 +430,139 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 }
 
+
+// The depth decoder's attention folded into the prologue of its output-projection matrix-vector product (round 3): a decoder
+// step sees at most 32 keys (one frame's codebooks), so the attention of ALL heads is a few thousand multiply-adds - cheaper to
+// recompute in every workgroup of the following product than to launch on its own (124 launches per generated frame, each
+// ~7.5 us of launch + ramp for ~0.3 us of work).  Every workgroup: rotates q and the new k (torchtune RoPE, interleaved pairs),
+// computes softmax(q K^T / sqrt(HD)) V over cache rows 0 .. pos-1 plus the new key / value taken from the qkv row, writes
+// the bf16 result into LDS as the product's input vector, then runs the usual row-per-wave product with the residual.
+// Workgroup 0 also appends the rotated k and the v of the new position to the caches (the others never read that row).
+// The arithmetic follows attn_decode_kernel operation for operation - the same products in the same order, the same
+// reduction trees (scores: one key per lane, a serial dot over HD; sum: a 64-lane butterfly; P.V: 16 key groups of 8-column
+// slices, groups summed ((g0+g1)+(g2+g3)) per quartet and the quartets left to right) - so a frame decoded through this
+// kernel is bit-identical to one decoded through csm_attn_decode_rope + csm_gemv_bf16 (tests/test_e2e_gpu.py).
+template <int NB, int HD>
+__global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                        const int* __restrict__ pos, const float* __restrict__ table,
+                                                        const bf16_t* __restrict__ W, bf16_t* __restrict__ y,
+                                                        const bf16_t* __restrict__ R, int N, int H, int KV, int S_max, int ldq,
+                                                        int ldw, int ldy, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    const int K = H * HD;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem_x);                         // [NB][K]   attention output = the product's input
+    float* qs = reinterpret_cast<float*>(smem_x + (size_t)NB * K * 2);      // [NB][H][HD]  rotated q (bf16-rounded values)
+    float* kn = qs + (size_t)NB * H * HD;                                   // [NB][KV][HD] rotated new k
+    float* pw = kn + (size_t)NB * KV * HD;                                  // [waves][64] probabilities
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rep = H / KV;
+    // ---- RoPE of q (all heads) and of the new k (all kv heads); workgroup 0 appends k, v to the caches
+    for (int it = threadIdx.x; it < NB * (H + KV) * (HD / 2); it += blockDim.x) {
+        const int i = it % (HD / 2), hh = (it / (HD / 2)) % (H + KV), b = it / ((HD / 2) * (H + KV));
+        const int p = pos[b];
+        const float c = table[((size_t)p * (HD / 2) + i) * 2], sn = table[((size_t)p * (HD / 2) + i) * 2 + 1];
+        const bf16_t* src = qkv + (size_t)b * ldq + hh * HD;                 // q heads, then k heads, contiguous in the fused row
+        const float x0 = bf2f(src[2 * i]), x1 = bf2f(src[2 * i + 1]);
+        const bf16_t r0 = f2bf(x0 * c - x1 * sn), r1 = f2bf(x1 * c + x0 * sn);
+        if (hh < H) {
+            qs[((size_t)b * H + hh) * HD + 2 * i] = bf2f(r0); qs[((size_t)b * H + hh) * HD + 2 * i + 1] = bf2f(r1);
+        } else {
+            const int kvh = hh - H;
+            kn[((size_t)b * KV + kvh) * HD + 2 * i] = bf2f(r0); kn[((size_t)b * KV + kvh) * HD + 2 * i + 1] = bf2f(r1);
+            if (blockIdx.x == 0) {
+                const bf16_t* vnew = qkv + (size_t)b * ldq + (H + KV + kvh) * HD;
+                const size_t dst = (((size_t)b * KV + kvh) * S_max + p) * HD;
+                kc[dst + 2 * i] = r0; kc[dst + 2 * i + 1] = r1;
+                vc[dst + 2 * i] = vnew[2 * i]; vc[dst + 2 * i + 1] = vnew[2 * i + 1];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- attention: one wave per (batch row, q head)
+    constexpr int LPR = HD / 8;                                              // lanes per value row (16)
+    const int sub = lane % LPR, gq = lane / LPR;                             // 8-column slice, group within a quartet
+    for (int hb = wave; hb < NB * H; hb += (int)(blockDim.x >> 6)) {
+        const int b = hb / H, h = hb % H, kvh = h / rep;
+        const int p = pos[b], n = p + 1;
+        const float* q = qs + ((size_t)b * H + h) * HD;
+        const float* knew = kn + ((size_t)b * KV + kvh) * HD;
+        const bf16_t* Kc = kc + ((size_t)b * KV + kvh) * S_max * HD;
+        const bf16_t* Vc = vc + ((size_t)b * KV + kvh) * S_max * HD;
+        const bf16_t* vnew = qkv + (size_t)b * ldq + (H + KV + kvh) * HD;
+        float d = 0.f;
+        if (lane < n) {
+            if (lane == p) {
+#pragma unroll 8
+                for (int c = 0; c < HD; ++c) d += q[c] * knew[c];
+            } else {
+                for (int c = 0; c < HD / 8; ++c) {
+                    float kf[8];
+                    unpack8(*reinterpret_cast<const U4*>(Kc + (size_t)lane * HD + c * 8), kf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += q[c * 8 + j] * kf[j];
+                }
+            }
+            d *= scale;
+        }
+        const float mx = wave_max(lane < n ? d : -INFINITY);
+        const float pr = lane < n ? __expf(d - mx) : 0.f;
+        const float sum = wave_sum(pr);
+        pw[wave * 64 + lane] = pr;                                           // (wave-private: a wave's own LDS operations are in order)
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                        // quartet r: key groups 4r .. 4r+3, mine is 4r + gq
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s_ = 4 * r + gq; s_ < n; s_ += 16) {
+                float vf[8];
+                unpack8(*reinterpret_cast<const U4*>((s_ == p ? vnew : Vc + (size_t)s_ * HD) + sub * 8), vf);
+                const float ps = pw[wave * 64 + s_];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += ps * vf[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] += __shfl_xor(acc[j], LPR, 64);
+                acc[j] += __shfl_xor(acc[j], 2 * LPR, 64);
+                o8[j] += acc[j];                                             // quartets left to right, starting from 0 (0 + W0 is exact)
+            }
+        }
+        if (gq == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[(size_t)b * K + h * HD + sub * 8 + j] = f2bf(o8[j] / sum);
+        }
+    }
+    __syncthreads();
+    // ---- y = attention . W^T (+ R): one wave per output row (gemv_kernel's loop)
+    const int wpb = blockDim.x >> 6;
+    for (int nrow = blockIdx.x * wpb + wave; nrow < N; nrow += gridDim.x * wpb) {
+        float acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+        const bf16_t* w = W + (size_t)nrow * ldw;
+        for (int k = lane * 8; k < K; k += 512) {
+            float wf[8];
+            unpack8(*reinterpret_cast<const U4*>(w + k), wf);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float xf[8];
+                unpack8(*reinterpret_cast<const U4*>(xs + b * K + k), xf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[b] += wf[j] * xf[j];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float v = wave_sum(acc[b]);
+            if (lane == 0) {
+                if (R) v += bf2f(R[(size_t)b * ldy + nrow]);
+                y[(size_t)b * ldy + nrow] = f2bf(v);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int gemv_launch(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
@@ -503,4 +643,24 @@ extern "C" int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache,
                                     int B, int H, int KV, int HD, int S_max, int ld, hipStream_t stream) {
     CSM_REQUIRE(rope_table, "csm_attn_decode_rope: null table");
     return attn_decode_launch(qkv, kcache, vcache, out, pos, rope_table, B, H, KV, HD, S_max, ld, stream);
+}
+
+// Decoder layer: rotate + cache append + attention over <= 64 cached positions + output projection (+ residual) in ONE launch;
+// bit-identical to csm_attn_decode_rope followed by csm_gemv_bf16 (same arithmetic, see gemv_attn_kernel).  HD = 128 only.
+extern "C" int csm_gemv_attn_bf16(const void* qkv, void* kcache, void* vcache, const int* pos, const float* rope_table, const void* W,
+                                  void* y, const void* residual, int B, int N, int H, int KV, int HD, int S_max, int ld_qkv, int ldw,
+                                  int ldy, hipStream_t stream) {
+    CSM_REQUIRE(qkv && kcache && vcache && pos && rope_table && W && y, "csm_gemv_attn_bf16: null pointer");
+    CSM_REQUIRE(B >= 1 && B <= 4 && N > 0 && H > 0 && KV > 0 && H % KV == 0 && HD == 128 && S_max >= 1 && S_max <= 64 && (ldw & 7) == 0 && (ld_qkv & 7) == 0,
+                "csm_gemv_attn_bf16: unsupported shape (B=%d H=%d KV=%d HD=%d S_max=%d: needs HD 128, S_max <= 64)", B, H, KV, HD, S_max);
+    const int K = H * HD;
+    const size_t lds = (size_t)B * K * 2 + ((size_t)B * H * HD + (size_t)B * KV * HD + 512) * sizeof(float);
+    CSM_REQUIRE(lds <= 65536, "csm_gemv_attn_bf16: %zu bytes of LDS needed", lds);
+    const int grid = N / 8 < 1 ? 1 : (N / 8 > 2048 ? 2048 : N / 8);      // 8 waves per workgroup: one (row, head) each in the prologue
+    const float scale = 1.f / sqrtf((float)HD);
+#define L(NB) hipLaunchKernelGGL((gemv_attn_kernel<NB, 128>), dim3(grid), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, pos, rope_table, (const bf16_t*)W, (bf16_t*)y, (const bf16_t*)residual, N, H, KV, S_max, ld_qkv, ldw, ldy, scale)
+    if (B == 1) L(1); else if (B == 2) L(2); else if (B == 3) L(3); else L(4);
+#undef L
+    CSM_CHECK_LAUNCH("csm_gemv_attn_bf16");
+    return 0;
 }

@@ -207,6 +207,12 @@ int csm_gemv_bf16_ex(const void* x, const void* W, void* y, const void* residual
 int csm_gemv_t_bf16(const void* x, const void* W, void* y, int B, int N, int K, int ldw, int ldx, int ldy, int out_f32,
                     csm_stream_t stream);
 /* caches are [B][KV][S_max][HD] bf16; pos = int32 [B] on the device (graph-replayable): the new key/value row index */
+/* a depth-decoder layer's rotate + cache append + attention (<= 64 cached positions, head_dim 128) + output projection
+ * (+ residual) as ONE launch: y[B][N] = attention(qkv row, caches) . W[N][H*HD]^T + residual; bit-identical to
+ * csm_attn_decode_rope followed by csm_gemv_bf16 (model.py:181-187 runs 31 such steps per frame). */
+int csm_gemv_attn_bf16(const void* qkv, void* kcache, void* vcache, const int* pos, const float* rope_table, const void* W, void* y,
+                       const void* residual, int B, int N, int H, int KV, int HD, int S_max, int ld_qkv, int ldw, int ldy,
+                       csm_stream_t stream);
 int csm_kv_append(const void* qkv, void* kcache, void* vcache, const int* pos, int B, int H, int KV, int HD, int S_max, int ld,
                   csm_stream_t stream);
 /* out[b][h*HD..] = softmax(q . K[0..pos[b]]^T / sqrt(HD)) V   for the single query row in qkv[b] */

@@ -651,6 +651,39 @@ def test_fused_decode_kernels_match_their_parts(dev):
         assert torch.equal(o1, o2), "fused rope + append + attention"
 
 
+def test_decoder_attention_fused_into_output_projection(dev):
+    """csm_gemv_attn_bf16 (a depth-decoder layer's rope + cache append + attention + output projection + residual in one
+    launch) against the two launches it replaces, csm_attn_decode_rope + csm_gemv_bf16, at the decoder's own geometry (8 q /
+    2 kv heads of 128, 32-slot cache, d = 1024) for every position of a frame and batch 1..4: same bits in the output AND in
+    the caches - so frames decoded through it are the frames the reference fixture pins."""
+    from csm.hip import ops
+    from csm.models.model import llama3_rope_table
+    g = torch.Generator().manual_seed(46)
+    H, KV, hd, S_max, d = 8, 2, 128, 32, 1024
+    table = llama3_rope_table(S_max, hd, 500000.0, 32.0).to(dev).contiguous()
+    W = (torch.randn(d, H * hd, generator=g) * 0.05).to(BF).to(dev)
+    for B in (1, 2, 4):
+        kc = torch.randn(B, KV, S_max, hd, generator=g).to(BF)
+        vc = torch.randn(B, KV, S_max, hd, generator=g).to(BF)
+        for p0 in (0, 1, 7, 16, 17, 30, 31):
+            posv = [(p0 + 5 * b) % S_max for b in range(B)]
+            pos = torch.tensor(posv, dtype=torch.int32, device=dev)
+            qkv = torch.randn(B, (H + 2 * KV) * hd, generator=g).to(BF).to(dev)
+            R = torch.randn(B, d, generator=g).to(BF).to(dev)
+            k1, v1, k2, v2 = kc.to(dev), vc.to(dev), kc.to(dev), vc.to(dev)
+            o = torch.empty(B, H * hd, dtype=BF, device=dev)
+            y1, y2 = torch.empty(B, d, dtype=BF, device=dev), torch.empty(B, d, dtype=BF, device=dev)
+            ops.attn_decode_rope(qkv, k1, v1, o, pos, table, H, KV, hd)
+            ops.gemv(o, W, y1, residual=R)
+            ops.gemv_attn(qkv, k2, v2, pos, table, W, y2, R, H, KV, hd)
+            assert torch.equal(k1, k2) and torch.equal(v1, v2), f"caches B={B} pos={posv}"
+            assert torch.equal(y1, y2), f"output B={B} pos={posv}: max diff {(y1.float() - y2.float()).abs().max().item()}"
+            y3 = torch.empty(B, d, dtype=BF, device=dev)
+            ops.gemv_attn(qkv, k2, v2, pos, table, W, y3, None, H, KV, hd)        # (append again: same bits; no residual)
+            ops.gemv(o, W, y1)
+            assert torch.equal(y1, y3)
+
+
 def test_batched_generation_matches_single(dev):
     """Two utterances with prompts of different lengths decoded together (ragged prefill into the rows of one KV cache,
     per-row positions) must sample exactly the frames each samples alone, given the same Exp(1) draws."""
