@@ -542,6 +542,27 @@ def main():
             extra[f"mode_{mode}"] = leg_summary(model, r, f"full-param, batch {a.batch}, loss mode {mode} ("
                                                 + ("semantic CE only = the reference's compute_loss" if mode == "A" else "depth decoder on every frame") + ")")
         model.acoustic_mode = "amortized"
+        # config 2's batch against its own rows: the loss of the B = 4 batch (reference loss, and with the depth decoder on pinned
+        # frames) must be the mean of the four single-sequence losses - each of those is the quantity parity_check ties to the
+        # CPU oracle below and tests/test_e2e_gpu.py ties to it on an S = 128 prefix
+        try:
+            per = torch.arange(0, a.seq - 1, 16)
+            nb = batch["input_tokens"].shape[0]
+            rows = torch.cat([per + b * (a.seq - 1) for b in range(nb)])
+            with torch.no_grad():
+                t4, d4 = compute_loss(model, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"], 100.0, 1.0, acoustic_rows=rows)
+                ones = [compute_loss(model, batch["input_tokens"][b:b + 1], batch["input_masks"][b:b + 1], batch["target_audio_tokens"][b:b + 1],
+                                     100.0, 1.0, acoustic_rows=per) for b in range(nb)]
+            m_sem = sum(float(o[1]["semantic_loss"]) for o in ones) / nb
+            m_ac = sum(float(o[1]["acoustic_loss"]) for o in ones) / nb
+            m_tot = sum(float(o[0]) for o in ones) / nb
+            extra["config2_b4_parity"] = {
+                "what": f"loss of the B={nb} batch vs the mean of its {nb} single-sequence losses (same weights, pinned decoder frames)",
+                "batch_total": float(t4), "mean_of_singles_total": m_tot, "rel_diff_total": abs(float(t4) - m_tot) / abs(m_tot),
+                "rel_diff_semantic": abs(float(d4["semantic_loss"]) - m_sem) / abs(m_sem),
+                "rel_diff_acoustic": abs(float(d4["acoustic_loss"]) - m_ac) / abs(m_ac)}
+        except Exception as e:  # noqa: BLE001 - an extra leg must never take the headline line down
+            extra["config2_b4_parity"] = {"error": repr(e)}
         # free the full-param trainer before the LoRA model is built
         del tr, res, gt
         lm = Model(args, device=f"cuda:{local}", seed=0)

@@ -4,18 +4,18 @@
 # The dense bf16 MFMA peak of 2.5 PFLOP/s is 256 CU x 4 SIMD x 1024 FLOP/clk at 2.4 GHz; what the step can reach scales
 # with the clock the chip sustains under this load.
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02
-OUT=gpurun_out/r02/clock_power_raw.txt
+mkdir -p gpurun_out/r03
+OUT=gpurun_out/r03/clock_power_raw.txt
 : > $OUT
 ( while true; do echo "t=$(date +%s.%N)" >> $OUT; rocm-smi -P -c -u --json >> $OUT 2>/dev/null; echo >> $OUT; sleep 0.25; done ) &
 SMI=$!
 sleep 2
-python3 bench.py --steps 120 --warmup 10 --no-cpu-baseline --no-extras > gpurun_out/r02/clock_power_bench.json 2> gpurun_out/r02/clock_power_bench.err
+python3 bench.py --steps 120 --warmup 10 --no-cpu-baseline --no-extras > gpurun_out/r03/clock_power_bench.json 2> gpurun_out/r03/clock_power_bench.err
 sleep 1
 kill $SMI
 python3 - <<'PY'
 import json, re
-raw = open("gpurun_out/r02/clock_power_raw.txt").read().split("t=")[1:]
+raw = open("gpurun_out/r03/clock_power_raw.txt").read().split("t=")[1:]
 rows = []
 for blk in raw:
     lines = blk.strip().split("\n")
@@ -32,7 +32,7 @@ for blk in raw:
         return None
     rows.append((t, num(r"sclk clock speed|sclk"), num(r"power"), num(r"GPU use")))
 t0 = rows[0][0]
-b = json.load(open("gpurun_out/r02/clock_power_bench.json"))
+b = json.load(open("gpurun_out/r03/clock_power_bench.json"))
 busy = [r for r in rows if r[3] is not None and r[3] >= 90]
 print(f"# rocm-smi trace while `bench.py --steps 120 --warmup 10` ran: {b['ms_per_step']} ms/step, {b['value']} tokens/s, mfma_utilisation_step {b['mfma_utilisation_step']}")
 print(f"# {len(rows)} samples, {len(busy)} with GPU use >= 90 %")
