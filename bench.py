@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--lora", action="store_true", help="configs[2]: LoRA r=8 q_proj/v_proj instead of full-param")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048, help="positions of the CPU-baseline sample (SURVEY 8d protocol: B=1, S=2048)")
-    ap.add_argument("--cpu-budget", type=float, default=270.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
+    ap.add_argument("--cpu-budget", type=float, default=340.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (loss modes A / B, LoRA B=8, generate 10 s)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only; the number is not the metric)")
     ap.add_argument("--dry-run", action="store_true",
