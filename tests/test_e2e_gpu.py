@@ -899,3 +899,26 @@ def test_full_size_lora_config3_properties(dev):
         m.lora = None
         merged, _ = compute_loss(m, *args)
     assert rel(merged, adapted) < 2e-3, (float(merged), float(adapted))
+
+
+def test_optimizer_follows_rewritten_weights(dev):
+    """The split fp32 master keeps its upper half IN the bf16 arena: anything that rewrites the working weights after the
+    optimiser exists - Model.load_state_dict, merge_lora_weights, GradSync.broadcast_parameters - must leave master == new
+    weights (no stale lower halves shifting every weight by up to one bf16 ulp), at fp32 where the loaded values were fp32."""
+    from csm.training.optim import FusedAdamW
+    m, _, _ = tiny_model(dev)
+    opt = FusedAdamW(m, {"backbone": 1e-3, "decoder": 1e-3, "embeddings": 1e-3, "other": 1e-3})
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=5)
+    from csm.training.utils import compute_loss
+    t, _ = compute_loss(m, tokens, mask, targets)
+    t.backward()
+    opt.step()                                                   # lower halves are now non-trivial
+    assert any(float(st["lo"].float().abs().max()) > 0 for st in opt.state.values() if "lo" in st) or not any("lo" in st for st in opt.state.values())
+    fresh = {k: (v.float() * 1.01 + 1e-4) for k, v in O.init_params(TINY, seed=77).items()}        # fp32 values, not bf16-representable
+    m.load_state_dict(fresh)
+    for name, master in opt.named_master():
+        assert torch.equal(master.cpu(), fresh[name]), f"{name}: master must be the loaded fp32 values"
+    bf = {k: v.to(torch.bfloat16) for k, v in fresh.items()}
+    m.load_state_dict(bf)
+    for name, master in opt.named_master():
+        assert torch.equal(master.cpu(), bf[name].float()), f"{name}: master must equal the new bf16 weights exactly"

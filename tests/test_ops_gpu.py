@@ -743,3 +743,65 @@ def test_rvq(dev):
     codes2 = torch.empty(1, 40, dtype=torch.int64, device=dev)
     ops.rvq_encode(cbs[0][codes[0].cpu()].to(dev).contiguous(), cbs[:1].to(dev).contiguous(), codes2, 1)
     assert torch.equal(codes2[0], codes[0])
+
+
+def test_gemm_epilogue_read_prefetch_changes_no_bit(dev):
+    """csm_set_gemm_tuning(0, v): the 256x256 kernel's touches of a fused epilogue's read operand (gate/up of the SwiGLU
+    backward, a bf16 residual - extra loads inside the K loop whose results are discarded, waited for with vmcnt counted one
+    higher) must leave every output bit as it is, for every operand layout, with several tiles per persistent workgroup."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(321)
+    M, d, F = 4096, 2048, 4096
+    dy, w2, gu = rnd((M, d), g).to(dev), rnd((d, F), g, 0.05).to(dev), rnd((M, 2 * F), g).to(dev)
+    cases = [("nt", rnd((M, 1024), g).to(dev), rnd((4096, 1024), g, 0.05).to(dev), False, False),
+             ("nn", rnd((M, 1024), g).to(dev), rnd((1024, 4096), g, 0.05).to(dev), False, True),
+             ("tn", rnd((2048, M), g).to(dev), rnd((2048, 4096), g, 0.05).to(dev), True, True)]
+    R = rnd((M, 4096), g).to(dev)
+    out = {}
+    try:
+        for v in (0, 1):
+            ops.lib.csm_set_gemm_tuning(0, v)
+            dgu = torch.empty(M, 2 * F, dtype=BF, device=dev)
+            ops.linear_dx_swiglu_bwd(dy, w2, gu, dgu)
+            res = [dgu]
+            for name, A, B, tA, tB in cases:
+                acc = R.clone()
+                ops.gemm(A, B, acc, acc, tA, tB, alpha=0.5)          # accumulate into an aliasing bf16 residual
+                res.append(acc)
+            out[v] = res
+    finally:
+        ops.lib.csm_set_gemm_tuning(0, 1)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    ref = torch.empty(M, 2 * F, dtype=BF, device=dev)                # and the fused result is still the unfused one's
+    dact = torch.empty(M, F, dtype=BF, device=dev)
+    ops.gemm(dy, w2, dact, None, False, True)
+    ops.swiglu_bwd(gu, dact, ref)
+    close("swiglu bwd fused vs unfused", out[1][0], ref, 2e-2)
+
+
+def test_adamw_skipped_step_on_device(dev):
+    """A negative clip coefficient on the device = "this optimiser step does not happen" (how a data-parallel step with
+    incomplete gradients is dropped on every rank without a host sync): parameters, master halves and moments keep their
+    bits, zero_grad is still honoured; a non-negative coefficient gives the ordinary update."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(5)
+    n = 8 * 1000
+    for split in (False, True):
+        p0 = (torch.randn(n, generator=g) * 0.1).to(BF).to(dev)
+        grad0 = (torch.randn(n, generator=g) * 0.01).to(BF).to(dev)
+        m0, v0 = torch.rand(n, generator=g).to(dev) * 0.01, torch.rand(n, generator=g).to(dev) * 1e-4
+        for coef, moved in ((-1.0, False), (0.5, True)):
+            p, grad, m, v = p0.clone(), grad0.clone(), m0.clone(), v0.clone()
+            nc = torch.tensor([3.0, coef], dtype=torch.float32, device=dev)
+            if split:
+                lo = torch.randint(0, 2 ** 15, (n,), generator=g).to(torch.int16).to(dev)
+                lo0 = lo.clone()
+                ops.adamw_step_split(lo, m, v, p, grad, 1e-3, 0.9, 0.999, 1e-8, 0.01, 3, nc, zero_grad=True)
+                assert torch.equal(lo, lo0) != moved
+            else:
+                master = p.float()
+                ops.adamw_step(master, m, v, p, grad, 1e-3, 0.9, 0.999, 1e-8, 0.01, 3, nc, zero_grad=True)
+                assert torch.equal(master, p0.float()) != moved
+            assert torch.equal(p, p0) != moved and torch.equal(m, m0) != moved and torch.equal(v, v0) != moved
+            assert float(grad.float().abs().max()) == 0.0, "zero_grad is honoured either way"
