@@ -235,6 +235,10 @@ int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int
                        long long sC, long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
                        hipStream_t stream, int epi_p0 = 0, int epi_p1 = 0, const void* xA = nullptr, const void* xB = nullptr, int kx = 0);
 
+int csm_gemm256w4_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
+                         int transA, int transB, int out_f32, float alpha, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
+                         hipStream_t stream, int epi_p0, int epi_p1);
+
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
 static bool prefer_256(int M, int N, int K, int batch) {
@@ -263,7 +267,7 @@ extern "C" int csm_set_gemm_tuning(int key, int value) {
 }
 
 extern "C" int csm_set_gemm_variant(int v) {
-    CSM_REQUIRE(v >= 0 && v <= 3, "csm_set_gemm_variant: %d is not one of 0..3", v);
+    CSM_REQUIRE(v >= 0 && v <= 4, "csm_set_gemm_variant: %d is not one of 0..4", v);
     g_gemm_variant = v;
     return 0;
 }
@@ -290,7 +294,11 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, i
     if (epilogue == 1) CSM_REQUIRE(!out_f32 && aux_out && (N & 3) == 0 && (ldc & 3) == 0 && ld_aux >= N / 2 && (ld_aux & 1) == 0, "csm_gemm_bf16_ex: bad SwiGLU-forward epilogue arguments");
     if (epilogue == 2) CSM_REQUIRE(!out_f32 && aux_in && (N & 3) == 0 && (ldc & 7) == 0 && (ld_aux & 7) == 0 && ld_aux >= 2 * N && !R && ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)C & 15) == 0, "csm_gemm_bf16_ex: bad SwiGLU-backward epilogue arguments");
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
-    if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 3 && K % 64 == 0 && M >= 8 && N >= 8))
+    // variant 4: the four-wave 256x256 kernel with the hand-scheduled K loop (gemm256w4.hip), where it applies
+    if (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8 && batch == 1 && kx == 0)
+        return csm_gemm256w4_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, epilogue, aux_in, aux_out,
+                                    ld_aux, stream, epi_p0, epi_p1);
+    if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant >= 3 && K % 64 == 0 && M >= 8 && N >= 8))
         return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
                                   strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1, xA, xB, kx);
     GemmArgs g;

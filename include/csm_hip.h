@@ -87,7 +87,8 @@ int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW1, int N1, 
 
 
 /* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = the 256x256 pipelined kernel
- * where its tiles fill the chip, else 128x128 (default); 3 force the 256x256 kernel */
+ * where its tiles fill the chip, else 128x128 (default); 3 force the 256x256 kernel; 4 force the four-wave 256x256 kernel
+ * with the hand-scheduled K loop where it applies (batch 1, no K-extension), else as 3 */
 int csm_set_gemm_variant(int v);
 /* tuning switch: 1 (default) the 256x256 kernel runs one persistent workgroup per CU over its tile list (the next tile's first
  * loads are requested before the finished tile is stored); 0 one tile per workgroup */

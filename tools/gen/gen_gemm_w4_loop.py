@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generates csrc/gemm256w4_loop.inc: the hand-scheduled K loop of the 4-wave 256x256 bf16 GEMM (gemm256w4.hip) as ONE
+inline-asm block per operand-layout pair.
+
+Why generated assembly: a 128 x 128 wave tile (four waves per workgroup, one per SIMD) needs 256 accumulator registers; hipcc's
+register allocator cannot keep them in AGPRs across a K loop written with the MFMA builtin (round 2: ~650 accvgpr moves and
+170 scratch accesses per two K-tiles).  Here the accumulators are a[0:255], owned by the asm block; the fragments live in
+v[64:191] (two sets, ping-pong per 32-deep k-step), and every LDS read, LDS-DMA request, wait and the one barrier per K-tile
+has a fixed slot between the MFMAs.
+
+Schedule of K-tile t (tile = 64 deep = 2 k-steps; A double-buffered, B triple-buffered in LDS, as in gemm256.hip):
+  ks0: 64 MFMAs on fragment set P | reads (t, ks1) -> set Q | LDS-DMA of B(t+2) (its stage held tile t-1: free)
+  s_waitcnt lgkmcnt(0); s_waitcnt vmcnt(8 | 0)  [my pieces of tile t+1 have landed]; s_barrier  [tile t+1 published, tile t's A stage free]
+  ks1: 64 MFMAs on Q | reads (t+1, ks0) -> P | LDS-DMA of A(t+2) into tile t's A stage
+Operands (see ASM_OPERANDS in gemm256w4.hip): %0 A lane address (LDS, stage 0, my half, k-step 0), %1 B lane address,
+%2 B tr key (T=1) / unused, %3..%18 LDS-DMA lane offsets [A0 x4, A1 x4, B0 x4, B1 x4], %19 A base ptr, %20 B base ptr,
+%21 A step, %22 B step, %23 nt, %24 wave * 4096.
+"""
+import sys
+
+# ---- fixed registers ------------------------------------------------------------------------------------------------
+PA, PB, QA, QB = 64, 96, 128, 160          # fragment sets: A tiles i at +4i, B tiles j at +4j
+VB = 192                                    # v[192:199] B per-n-tile lane addresses (T=1), stage 0;  v192 for T=0
+VBC = 200                                   # v[200:207] the same + current stage
+VAC0, VAC1 = 208, 209                       # A current-stage lane addresses, k-step 0 / 1
+VBT0, VBT1 = 210, 211                       # B (T=0) current-stage lane addresses, k-step 0 / 1
+VA1 = 212                                   # A stage-0 k-step 1 address (T=0)
+VB1 = 213                                   # B stage-0 k-step 1 address (T=0)
+VAT = 214                                   # v[214:221] A per-m-tile lane addresses (T=1), stage 0
+VATC = 222                                  # v[222:229] the same + current stage
+S_RA, S_RB = 40, 44                         # buffer resource descriptors (4 SGPRs each)
+S_STA, S_STB = 48, 50                       # steps (64-bit)
+S_T, S_NT, S_SLA, S_SLB, S_TMP, S_WOFF, S_B3, S_T2 = 52, 53, 54, 55, 56, 57, 58, 59
+S_LA, S_LB = 60, 61                         # LDS byte offsets of the CURRENT tile's A / B stage (for the reads)
+
+
+def frag_reads(T, dst, cur0, cur1, curt, ks):
+    """LDS reads of 8 tiles' fragments for k-step ks into registers dst + 4 * tile."""
+    out = []
+    for i in range(8):
+        r = dst + 4 * i
+        if T == 0:
+            out.append(f"ds_read_b128 v[{r}:{r + 3}], v{cur1 if ks else cur0} offset:{i * 2048}")
+        else:
+            out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{curt + i} offset:{ks * 8192}")
+            out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{curt + i} offset:{ks * 8192 + 1024}")
+    return out
+
+
+def dma_half(which, h, op_base):
+    """my 4 pieces of half-tile h of operand `which` ('A' | 'B') for the tile the resource descriptor points at"""
+    out = []
+    rs = S_RA if which == "A" else S_RB
+    sl = S_SLA if which == "A" else S_SLB
+    for i in range(4):
+        out.append(f"s_add_u32 m0, s{sl}, {h * 16384 + i * 1024}")
+        out.append("s_nop 0")
+        out.append(f"buffer_load_dwordx4 %{op_base + 4 * h + i}, s[{rs}:{rs + 3}], 0 offen lds")
+    return out
+
+
+def mfmas(sa, sb):
+    out = []
+    for i in range(8):
+        for j in range(8):
+            c = (i * 8 + j) * 4
+            out.append(f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], v[{sb + 4 * j}:{sb + 4 * j + 3}], v[{sa + 4 * i}:{sa + 4 * i + 3}], a[{c}:{c + 3}]")
+    return out
+
+
+def interleave(mf, side):
+    """side instructions spread evenly between the MFMAs (first one after the first MFMA)"""
+    out = []
+    n, m = len(mf), len(side)
+    k = 0
+    for idx, ins in enumerate(mf):
+        out.append(ins)
+        want = (idx + 1) * m // n
+        while k < want:
+            out.append(side[k]); k += 1
+    out += side[k:]
+    return out
+
+
+def set_cur(TA, TB):
+    """lane addresses of the current tile's stages (s60 / s61 = LDS byte offsets of its A / B stage)"""
+    out = []
+    if TA == 0:
+        out += [f"v_add_u32 v{VAC0}, s{S_LA}, %0", f"v_add_u32 v{VAC1}, s{S_LA}, v{VA1}"]
+    else:
+        out += [f"v_add_u32 v{VATC + i}, s{S_LA}, v{VAT + i}" for i in range(8)]
+    if TB == 0:
+        out += [f"v_add_u32 v{VBT0}, s{S_LB}, %1", f"v_add_u32 v{VBT1}, s{S_LB}, v{VB1}"]
+    else:
+        out += [f"v_add_u32 v{VBC + j}, s{S_LB}, v{VB + j}" for j in range(8)]
+    return out
+
+
+def next_stage_offsets():
+    """s60 / s61 -> stage of tile t+1 (A alternates 0 / 32768; B cycles 65536 + {0, 32768, 65536} by s58 = (t+1) % 3)"""
+    return [f"s_xor_b32 s{S_LA}, s{S_LA}, 0x8000",
+            f"s_add_u32 s{S_B3}, s{S_B3}, 1", f"s_cmp_eq_u32 s{S_B3}, 3", f"s_cselect_b32 s{S_B3}, 0, s{S_B3}",
+            f"s_lshl_b32 s{S_LB}, s{S_B3}, 15", f"s_add_u32 s{S_LB}, s{S_LB}, 0x10000"]
+
+
+def gen(TA, TB):
+    L = []
+    e = L.append
+    # ---- set-up: resource descriptors, constants, per-tile addresses
+    e(f"s_mov_b64 s[{S_RA}:{S_RA + 1}], %19"); e(f"s_mov_b32 s{S_RA + 2}, -1"); e(f"s_mov_b32 s{S_RA + 3}, 0x00020000")
+    e(f"s_mov_b64 s[{S_RB}:{S_RB + 1}], %20"); e(f"s_mov_b32 s{S_RB + 2}, -1"); e(f"s_mov_b32 s{S_RB + 3}, 0x00020000")
+    e(f"s_and_b32 s{S_RA + 1}, s{S_RA + 1}, 0xffff"); e(f"s_and_b32 s{S_RB + 1}, s{S_RB + 1}, 0xffff")
+    e(f"s_mov_b64 s[{S_STA}:{S_STA + 1}], %21"); e(f"s_mov_b64 s[{S_STB}:{S_STB + 1}], %22")
+    e(f"s_mov_b32 s{S_NT}, %23"); e(f"s_mov_b32 s{S_WOFF}, %24")
+    if TA == 0:
+        e(f"v_xor_b32 v{VA1}, 64, %0")
+    else:
+        for i in range(8):
+            e(f"v_xor_b32 v{VAT + i}, {i}, %2"); e(f"v_lshl_add_u32 v{VAT + i}, v{VAT + i}, 5, %0")
+    if TB == 0:
+        e(f"v_xor_b32 v{VB1}, 64, %1")
+    else:
+        for j in range(8):
+            e(f"v_xor_b32 v{VB + j}, {j}, %2"); e(f"v_lshl_add_u32 v{VB + j}, v{VB + j}, 5, %1")
+    for n in range(256):
+        e(f"v_accvgpr_write_b32 a{n}, 0")
+    # ---- prologue: K-tiles 0 and 1 (A stage 0 / 1, B stage 0 / 1), then fragments (0, ks0) -> P
+    e(f"s_mov_b32 s{S_SLA}, s{S_WOFF}"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x10000")
+    L += dma_half("A", 0, 3) + dma_half("A", 1, 3) + dma_half("B", 0, 11) + dma_half("B", 1, 11)
+    e(f"s_cmp_lt_u32 s{S_NT}, 2"); e("s_cbranch_scc1 10f")
+    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):
+        e(f"s_add_u32 s{rs}, s{rs}, s{st}"); e(f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}")
+    e(f"s_add_u32 s{S_SLA}, s{S_WOFF}, 0x8000"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x18000")
+    L += dma_half("A", 0, 3) + dma_half("A", 1, 3) + dma_half("B", 0, 11) + dma_half("B", 1, 11)
+    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):                                   # descriptors now point at K-tile 2
+        e(f"s_add_u32 s{rs}, s{rs}, s{st}"); e(f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}")
+    e("s_waitcnt vmcnt(16)"); e("s_branch 11f")
+    e("10:"); e("s_waitcnt vmcnt(0)")
+    e("11:"); e("s_barrier")
+    e(f"s_mov_b32 s{S_T}, 0"); e(f"s_mov_b32 s{S_B3}, 0"); e(f"s_mov_b32 s{S_LA}, 0"); e(f"s_mov_b32 s{S_LB}, 0x10000")
+    L += set_cur(TA, TB)
+    L += frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
+    e("s_waitcnt lgkmcnt(0)")
+    # ---- the loop: one K-tile per trip
+    e("1:")
+    e(f"s_add_u32 s{S_T2}, s{S_T}, 2")
+    # stage of tile t+2: A = the current tile's A stage (s60), B = 65536 + ((t+2) % 3) * 32768 = the stage of tile t-1
+    side0 = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
+    # B(t+2) requests, skipped (branch) when t+2 >= nt: emitted as a separate straight-line group in the middle of ks0
+    mf0 = mfmas(PA, PB)
+    half = len(mf0) // 2
+    L += interleave(mf0[:half], side0)
+    e(f"s_cmp_lt_u32 s{S_T2}, s{S_NT}"); e("s_cbranch_scc0 2f")
+    # s59 (t+2) % 3 is not kept: B stage of t+2 = stage of t-1 = (s58 + 2) % 3
+    e(f"s_add_u32 s{S_TMP}, s{S_B3}, 2"); e(f"s_cmp_ge_u32 s{S_TMP}, 3"); e(f"s_cselect_b32 s{S_TMP}, {-3 & 0xffffffff}, 0")
+    e(f"s_add_u32 s{S_TMP}, s{S_TMP}, s{S_B3}"); e(f"s_add_u32 s{S_TMP}, s{S_TMP}, 2")
+    e(f"s_lshl_b32 s{S_SLB}, s{S_TMP}, 15"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFF}")
+    dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
+    L += interleave(mf0[half:], dmaB)
+    e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(8)"); e("s_branch 3f")
+    e("2:")
+    L += mf0[half:]
+    e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(0)")
+    e("3:"); e("s_barrier")
+    # ---- ks1: fragments of (t+1, ks0) -> P and A(t+2) into the stage tile t just left
+    e(f"s_add_u32 s{S_SLA}, s{S_LA}, s{S_WOFF}")                                     # A stage of tile t (free now) for the t+2 requests
+    L += next_stage_offsets()
+    e(f"s_add_u32 s{S_TMP}, s{S_T}, 1"); e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}"); e("s_cbranch_scc0 5f")
+    side1 = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
+    mf1 = mfmas(QA, QB)
+    L += interleave(mf1[:half], side1)
+    e(f"s_cmp_lt_u32 s{S_T2}, s{S_NT}"); e("s_cbranch_scc0 4f")
+    dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3)
+    adv = []
+    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):
+        adv += [f"s_add_u32 s{rs}, s{rs}, s{st}", f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}"]
+    L += interleave(mf1[half:], dmaA + adv)
+    e("s_branch 6f")
+    e("4:")
+    L += mf1[half:]
+    e("s_branch 6f")
+    e("5:")                                                                        # last K-tile: nothing to fetch
+    L += mf1
+    e("6:")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_add_u32 s{S_T}, s{S_T}, 1"); e(f"s_cmp_lt_u32 s{S_T}, s{S_NT}"); e("s_cbranch_scc1 1b")
+    e("s_nop 7"); e("s_nop 7"); e("s_nop 3")                                       # last MFMA results before v_accvgpr_read
+    return L
+
+
+def main(path):
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen/gen_gemm_w4_loop.py - do not edit.  The K loop of gemm256w4.hip as inline-asm text,\n"
+                "// one macro per operand-layout pair (TA, TB: 0 = K-contiguous LDS image, 1 = K-strided image).\n")
+        for TA in (0, 1):
+            for TB in (0, 1):
+                body = gen(TA, TB)
+                f.write(f"#define CSM_W4_LOOP_{TA}{TB} \\\n")
+                for ins in body:
+                    f.write(f'    "{ins}\\n\\t" \\\n')
+                f.write('    ""\n')
+        f.write("#define CSM_W4_CLOBBERS " + ", ".join([f'"v{n}"' for n in range(64, 230)] + [f'"a{n}"' for n in range(256)] +
+                                                      [f'"s{n}"' for n in range(40, 62)] + ['"m0"', '"scc"', '"vcc"', '"memory"']) + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
