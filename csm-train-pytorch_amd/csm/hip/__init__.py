@@ -97,6 +97,8 @@ if os.environ.get("CSM_GEMM256_PERSISTENT") == "0":     # kernel A/B only (tools
     lib.csm_set_gemm256_persistent(0)
 if os.environ.get("CSM_GEMM_TOUCH") == "0":             # kernel A/B only (tools/probes)
     lib.csm_set_gemm_tuning(0, 0)
+if os.environ.get("CSM_GEMM_W4") == "0":                # kernel A/B only (tools/probes)
+    lib.csm_set_gemm_tuning(1, 0)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -241,6 +241,7 @@ int csm_gemm256w4_launch(const void* A, const void* B, void* C, const void* R, i
 
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
+int g_gemm_w4 = 1;     // csm_set_gemm_tuning(1, v)
 static bool prefer_256(int M, int N, int K, int batch) {
     if (K % 64 != 0 || M < 8 || N < 8) return false;
     const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
@@ -258,11 +259,13 @@ extern "C" int csm_set_gemm256_persistent(int v) { g_persistent = v ? 1 : 0; ret
 extern "C" int csm_get_gemm256_persistent(void) { return g_persistent; }
 extern "C" const char* csm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
-// tuning switches of the 256x256 kernel for A/B runs: key 0 = epilogue-read prefetch (default 1)
+// tuning switches of the 256x256 kernels for A/B runs: key 0 = epilogue-read prefetch of the eight-wave kernel (default 1);
+// key 1 = the auto variant gives batch-1 products without K-extension to the four-wave kernel (default 1)
 extern int g_gemm_touch;
 extern "C" int csm_set_gemm_tuning(int key, int value) {
-    CSM_REQUIRE(key == 0, "csm_set_gemm_tuning: unknown key %d", key);
-    g_gemm_touch = value ? 1 : 0;
+    CSM_REQUIRE(key == 0 || key == 1, "csm_set_gemm_tuning: unknown key %d", key);
+    if (key == 0) g_gemm_touch = value ? 1 : 0;
+    else g_gemm_w4 = value ? 1 : 0;
     return 0;
 }
 
@@ -295,7 +298,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, i
     if (epilogue == 2) CSM_REQUIRE(!out_f32 && aux_in && (N & 3) == 0 && (ldc & 7) == 0 && (ld_aux & 7) == 0 && ld_aux >= 2 * N && !R && ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)C & 15) == 0, "csm_gemm_bf16_ex: bad SwiGLU-backward epilogue arguments");
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     // variant 4: the four-wave 256x256 kernel with the hand-scheduled K loop (gemm256w4.hip), where it applies
-    if (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8 && batch == 1 && kx == 0)
+    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && batch == 1 && kx == 0)
         return csm_gemm256w4_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, epilogue, aux_in, aux_out,
                                     ld_aux, stream, epi_p0, epi_p1);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant >= 3 && K % 64 == 0 && M >= 8 && N >= 8))

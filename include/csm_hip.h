@@ -94,8 +94,9 @@ int csm_set_gemm_variant(int v);
  * loads are requested before the finished tile is stored); 0 one tile per workgroup */
 int csm_set_gemm256_persistent(int v);
 int csm_get_gemm256_persistent(void);
-/* tuning switch for A/B runs: key 0 = the 256x256 kernel touches the tile of a fused epilogue's read operand (gate/up of the
- * SwiGLU backward, a bf16 residual) during its last K-tiles so that the epilogue's loads hit cache (default 1) */
+/* tuning switches for A/B runs: key 0 = the eight-wave 256x256 kernel touches the tile of a fused epilogue's read operand
+ * (gate/up of the SwiGLU backward, a bf16 residual) during its K loop so that the epilogue's loads hit cache (default 1);
+ * key 1 = the auto variant hands batch-1 products without K-extension to the four-wave kernel (default 1) */
 int csm_set_gemm_tuning(int key, int value);
 /* name of the kernel (rocprofv3 spelling, without the argument list) the most recent csm_gemm_* call on this host thread's
  * library instance launched - for benchmarks that attribute time to kernels; not thread-safe */
