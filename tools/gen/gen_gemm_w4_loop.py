@@ -68,17 +68,42 @@ def mfmas(sa, sb):
     return out
 
 
-def interleave(mf, side):
-    """side instructions spread evenly between the MFMAs (first one after the first MFMA)"""
+def interleave(mf, side, first=0, last=None):
+    """side instructions spread evenly over MFMAs [first, last) of the list (the first one after MFMA `first`)"""
     out = []
-    n, m = len(mf), len(side)
+    last = len(mf) if last is None else last
+    n, m = last - first, len(side)
     k = 0
     for idx, ins in enumerate(mf):
         out.append(ins)
-        want = (idx + 1) * m // n
-        while k < want:
-            out.append(side[k]); k += 1
+        if first <= idx < last:
+            want = (idx - first + 1) * m // n
+            while k < want:
+                out.append(side[k]); k += 1
     out += side[k:]
+    return out
+
+
+def merge(a, b):
+    """two instruction streams already interleaved with the same MFMA list: not used"""
+    raise NotImplementedError
+
+
+def weave(mf, streams):
+    """several side streams, each (instructions, first MFMA, last MFMA), woven between the MFMAs of one phase"""
+    slots = [[] for _ in mf]
+    for side, first, last in streams:
+        n, m = last - first, len(side)
+        k = 0
+        for idx in range(first, last):
+            want = (idx - first + 1) * m // n
+            while k < want:
+                slots[idx].append(side[k]); k += 1
+        slots[last - 1] += side[k:]
+    out = []
+    for ins, sl in zip(mf, slots):
+        out.append(ins)
+        out += sl
     return out
 
 
@@ -124,19 +149,24 @@ def gen(TA, TB):
             e(f"v_xor_b32 v{VB + j}, {j}, %2"); e(f"v_lshl_add_u32 v{VB + j}, v{VB + j}, 5, %1")
     for n in range(256):
         e(f"v_accvgpr_write_b32 a{n}, 0")
+    adv = []
+    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):
+        adv += [f"s_add_u32 s{rs}, s{rs}, s{st}", f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}"]
+    # The loop is branch-free: a request for a K-tile past the last one goes through a descriptor with ZERO records (the range
+    # check drops it: no memory traffic, and it still counts in vmcnt), a fragment read past the last tile returns stale bytes
+    # nobody multiplies - so every wave issues the same instructions every trip and the waits are constants.
+    def set_records(tile_reg_or_imm):
+        return [f"s_cmp_lt_u32 {tile_reg_or_imm}, s{S_NT}", f"s_cselect_b32 s{S_TMP}, -1, 0",
+                f"s_mov_b32 s{S_RA + 2}, s{S_TMP}", f"s_mov_b32 s{S_RB + 2}, s{S_TMP}"]
     # ---- prologue: K-tiles 0 and 1 (A stage 0 / 1, B stage 0 / 1), then fragments (0, ks0) -> P
     e(f"s_mov_b32 s{S_SLA}, s{S_WOFF}"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x10000")
     L += dma_half("A", 0, 3) + dma_half("A", 1, 3) + dma_half("B", 0, 11) + dma_half("B", 1, 11)
-    e(f"s_cmp_lt_u32 s{S_NT}, 2"); e("s_cbranch_scc1 10f")
-    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):
-        e(f"s_add_u32 s{rs}, s{rs}, s{st}"); e(f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}")
+    L += adv
+    L += set_records("1")
     e(f"s_add_u32 s{S_SLA}, s{S_WOFF}, 0x8000"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x18000")
     L += dma_half("A", 0, 3) + dma_half("A", 1, 3) + dma_half("B", 0, 11) + dma_half("B", 1, 11)
-    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):                                   # descriptors now point at K-tile 2
-        e(f"s_add_u32 s{rs}, s{rs}, s{st}"); e(f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}")
-    e("s_waitcnt vmcnt(16)"); e("s_branch 11f")
-    e("10:"); e("s_waitcnt vmcnt(0)")
-    e("11:"); e("s_barrier")
+    L += adv                                                                        # descriptors now point at K-tile 2
+    e("s_waitcnt vmcnt(16)"); e("s_barrier")
     e(f"s_mov_b32 s{S_T}, 0"); e(f"s_mov_b32 s{S_B3}, 0"); e(f"s_mov_b32 s{S_LA}, 0"); e(f"s_mov_b32 s{S_LB}, 0x10000")
     L += set_cur(TA, TB)
     L += frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
@@ -144,44 +174,22 @@ def gen(TA, TB):
     # ---- the loop: one K-tile per trip
     e("1:")
     e(f"s_add_u32 s{S_T2}, s{S_T}, 2")
-    # stage of tile t+2: A = the current tile's A stage (s60), B = 65536 + ((t+2) % 3) * 32768 = the stage of tile t-1
-    side0 = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
-    # B(t+2) requests, skipped (branch) when t+2 >= nt: emitted as a separate straight-line group in the middle of ks0
-    mf0 = mfmas(PA, PB)
-    half = len(mf0) // 2
-    L += interleave(mf0[:half], side0)
-    e(f"s_cmp_lt_u32 s{S_T2}, s{S_NT}"); e("s_cbranch_scc0 2f")
-    # s59 (t+2) % 3 is not kept: B stage of t+2 = stage of t-1 = (s58 + 2) % 3
-    e(f"s_add_u32 s{S_TMP}, s{S_B3}, 2"); e(f"s_cmp_ge_u32 s{S_TMP}, 3"); e(f"s_cselect_b32 s{S_TMP}, {-3 & 0xffffffff}, 0")
-    e(f"s_add_u32 s{S_TMP}, s{S_TMP}, s{S_B3}"); e(f"s_add_u32 s{S_TMP}, s{S_TMP}, 2")
-    e(f"s_lshl_b32 s{S_SLB}, s{S_TMP}, 15"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFF}")
+    L += set_records(f"s{S_T2}")
+    # B stage of tile t+2 = the stage tile t-1 used = (s58 + 2) % 3
+    e(f"s_add_u32 s{S_TMP}, s{S_B3}, 2"); e(f"s_cmp_ge_u32 s{S_TMP}, 3"); e(f"s_cselect_b32 s{S_SLB}, {-3 & 0xffffffff}, 0")
+    e(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_TMP}")
+    e(f"s_lshl_b32 s{S_SLB}, s{S_SLB}, 15"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFF}")
+    # ks0: fragments (t, ks1) -> Q within the first 44 MFMAs, the 8 B(t+2) requests spread over all 64
+    reads_q = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
     dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
-    L += interleave(mf0[half:], dmaB)
-    e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(8)"); e("s_branch 3f")
-    e("2:")
-    L += mf0[half:]
-    e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(0)")
-    e("3:"); e("s_barrier")
+    L += weave(mfmas(PA, PB), [(reads_q, 0, 44), (dmaB, 2, 64)])
+    e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(8)"); e("s_barrier")
     # ---- ks1: fragments of (t+1, ks0) -> P and A(t+2) into the stage tile t just left
     e(f"s_add_u32 s{S_SLA}, s{S_LA}, s{S_WOFF}")                                     # A stage of tile t (free now) for the t+2 requests
     L += next_stage_offsets()
-    e(f"s_add_u32 s{S_TMP}, s{S_T}, 1"); e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}"); e("s_cbranch_scc0 5f")
-    side1 = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
-    mf1 = mfmas(QA, QB)
-    L += interleave(mf1[:half], side1)
-    e(f"s_cmp_lt_u32 s{S_T2}, s{S_NT}"); e("s_cbranch_scc0 4f")
-    dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3)
-    adv = []
-    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):
-        adv += [f"s_add_u32 s{rs}, s{rs}, s{st}", f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}"]
-    L += interleave(mf1[half:], dmaA + adv)
-    e("s_branch 6f")
-    e("4:")
-    L += mf1[half:]
-    e("s_branch 6f")
-    e("5:")                                                                        # last K-tile: nothing to fetch
-    L += mf1
-    e("6:")
+    reads_p = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
+    dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3) + adv
+    L += weave(mfmas(QA, QB), [(reads_p, 0, 44), (dmaA, 2, 64)])
     e("s_waitcnt lgkmcnt(0)")
     e(f"s_add_u32 s{S_T}, s{S_T}, 1"); e(f"s_cmp_lt_u32 s{S_T}, s{S_NT}"); e("s_cbranch_scc1 1b")
     e("s_nop 7"); e("s_nop 7"); e("s_nop 3")                                       # last MFMA results before v_accvgpr_read
@@ -200,7 +208,7 @@ def main(path):
                     f.write(f'    "{ins}\\n\\t" \\\n')
                 f.write('    ""\n')
         f.write("#define CSM_W4_CLOBBERS " + ", ".join([f'"v{n}"' for n in range(64, 230)] + [f'"a{n}"' for n in range(256)] +
-                                                      [f'"s{n}"' for n in range(40, 62)] + ['"m0"', '"scc"', '"vcc"', '"memory"']) + "\n")
+                                                      [f'"s{n}"' for n in range(40, 62)] + ['"scc"', '"vcc"', '"memory"']) + "\n")
 
 
 if __name__ == "__main__":
