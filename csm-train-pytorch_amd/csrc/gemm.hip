@@ -242,13 +242,13 @@ int csm_gemm256w4_launch(const void* A, const void* B, void* C, const void* R, i
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
 int g_gemm_w4 = 1;     // csm_set_gemm_tuning(1, v)
-static bool prefer_256(int M, int N, int K, int batch) {
+static bool prefer_256(int M, int N, int K, int batch, double need = 0.80) {
     if (K % 64 != 0 || M < 8 || N < 8) return false;
     const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const long long rounds = (tiles + 255) / 256;
     const double fill = (double)tiles / (double)(rounds * 256);
     const double area = ((double)M * N * batch) / ((double)tiles * 65536.0);
-    return fill * area >= 0.80;
+    return fill * area >= need;
 }
 
 // tuning / A-B switch (tools/gemm_bench.py, tests): 0 = 128x128 kernel with register staging, 1 = 128x128 kernel with
@@ -298,7 +298,8 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, i
     if (epilogue == 2) CSM_REQUIRE(!out_f32 && aux_in && (N & 3) == 0 && (ldc & 7) == 0 && (ld_aux & 7) == 0 && ld_aux >= 2 * N && !R && ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)C & 15) == 0, "csm_gemm_bf16_ex: bad SwiGLU-backward epilogue arguments");
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     // variant 4: the four-wave 256x256 kernel with the hand-scheduled K loop (gemm256w4.hip), where it applies
-    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && batch == 1 && kx == 0)
+    // (the four-wave kernel beats the 128x128 one from 1.5 rounds of tiles on: fused q|k|v forward, 384 tiles, 97 vs 115 us)
+    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch, 0.70)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && batch == 1 && kx == 0)
         return csm_gemm256w4_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, epilogue, aux_in, aux_out,
                                     ld_aux, stream, epi_p0, epi_p1);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant >= 3 && K % 64 == 0 && M >= 8 && N >= 8))
@@ -420,6 +421,9 @@ int csm_gemm256_two_wgrad_launch(const void* dY1, const void* X1, void* dW1, int
 
 // Two weight gradients that share the token dimension M, in ONE launch of 256x256 tiles (autograd's dW = dY^T X of two
 // nn.Linear layers; reference loop src/csm/training/trainer.py:261-263).  For outputs too small to fill 256 CUs alone.
+int csm_gemm256w4_two_wgrad_launch(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
+                                   const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
+                                   int M, int accumulate, float alpha, hipStream_t stream);
 extern "C" int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
                                        const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
                                        int M, int accumulate, float alpha, hipStream_t stream) {
@@ -430,6 +434,9 @@ extern "C" int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW
                 ldx2 >= K2 && ld_dw2 >= K2, "csm_gemm_bf16_two_wgrad: bad leading dimensions");
     CSM_REQUIRE((((uintptr_t)dY1 | (uintptr_t)X1 | (uintptr_t)dW1 | (uintptr_t)dY2 | (uintptr_t)X2 | (uintptr_t)dW2) & 15) == 0,
                 "csm_gemm_bf16_two_wgrad: operands must be 16-byte aligned");
+    if (g_gemm_w4 && g_gemm_variant != 3)
+        return csm_gemm256w4_two_wgrad_launch(dY1, X1, dW1, N1, K1, ld_dy1, ldx1, ld_dw1, dY2, X2, dW2, N2, K2, ld_dy2, ldx2, ld_dw2, M,
+                                              accumulate, alpha, stream);
     return csm_gemm256_two_wgrad_launch(dY1, X1, dW1, N1, K1, ld_dy1, ldx1, ld_dw1, dY2, X2, dW2, N2, K2, ld_dy2, ldx2, ld_dw2, M,
                                         accumulate, alpha, stream);
 }
