@@ -128,15 +128,54 @@ def next_stage_offsets():
             f"s_lshl_b32 s{S_LB}, s{S_B3}, 15", f"s_add_u32 s{S_LB}, s{S_LB}, 0x10000"]
 
 
-def gen(TA, TB):
+ADV = []
+for _rs, _st in ((S_RA, S_STA), (S_RB, S_STB)):
+    ADV += [f"s_add_u32 s{_rs}, s{_rs}, s{_st}", f"s_addc_u32 s{_rs + 1}, s{_rs + 1}, s{_st + 1}"]
+
+# touch state (epilogue-read prefetch): s62 countdown, s63 period - 1, s64 touches left, s[66:67] byte stride; v230 junk, v[232:233] address
+S_TCD, S_TPER, S_TLEFT, S_TSTR = 62, 63, 64, 66
+V_JUNK, V_TADDR = 230, 232
+
+
+def set_records(tile_reg_or_imm):
+    """descriptors get -1 records when the K-tile exists, 0 (every request dropped by the range check) when it does not"""
+    return [f"s_cmp_lt_u32 {tile_reg_or_imm}, s{S_NT}", f"s_cselect_b32 s{S_TMP}, -1, 0",
+            f"s_mov_b32 s{S_RA + 2}, s{S_TMP}", f"s_mov_b32 s{S_RB + 2}, s{S_TMP}"]
+
+
+def descriptors(opA, opB, opStA, opStB, opNt, opWoff):
     L = []
     e = L.append
-    # ---- set-up: resource descriptors, constants, per-tile addresses
-    e(f"s_mov_b64 s[{S_RA}:{S_RA + 1}], %19"); e(f"s_mov_b32 s{S_RA + 2}, -1"); e(f"s_mov_b32 s{S_RA + 3}, 0x00020000")
-    e(f"s_mov_b64 s[{S_RB}:{S_RB + 1}], %20"); e(f"s_mov_b32 s{S_RB + 2}, -1"); e(f"s_mov_b32 s{S_RB + 3}, 0x00020000")
+    e(f"s_mov_b64 s[{S_RA}:{S_RA + 1}], %{opA}"); e(f"s_mov_b32 s{S_RA + 2}, -1"); e(f"s_mov_b32 s{S_RA + 3}, 0x00020000")
+    e(f"s_mov_b64 s[{S_RB}:{S_RB + 1}], %{opB}"); e(f"s_mov_b32 s{S_RB + 2}, -1"); e(f"s_mov_b32 s{S_RB + 3}, 0x00020000")
     e(f"s_and_b32 s{S_RA + 1}, s{S_RA + 1}, 0xffff"); e(f"s_and_b32 s{S_RB + 1}, s{S_RB + 1}, 0xffff")
-    e(f"s_mov_b64 s[{S_STA}:{S_STA + 1}], %21"); e(f"s_mov_b64 s[{S_STB}:{S_STB + 1}], %22")
-    e(f"s_mov_b32 s{S_NT}, %23"); e(f"s_mov_b32 s{S_WOFF}, %24")
+    e(f"s_mov_b64 s[{S_STA}:{S_STA + 1}], %{opStA}"); e(f"s_mov_b64 s[{S_STB}:{S_STB + 1}], %{opStB}")
+    e(f"s_mov_b32 s{S_NT}, %{opNt}"); e(f"s_mov_b32 s{S_WOFF}, %{opWoff}")
+    return L
+
+
+def gen_pro():
+    """The first two K-tiles of an output tile (A stage 0 / 1, B stage 0 / 1): requests only, no wait.  Operands: %0..%15 LDS-DMA
+    lane offsets [A0 x4, A1 x4, B0 x4, B1 x4], %16 A base, %17 B base, %18 A step, %19 B step, %20 nt, %21 wave LDS offset."""
+    L = descriptors(16, 17, 18, 19, 20, 21)
+    e = L.append
+    e(f"s_mov_b32 s{S_SLA}, s{S_WOFF}"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x10000")
+    L += dma_half("A", 0, 0) + dma_half("A", 1, 0) + dma_half("B", 0, 8) + dma_half("B", 1, 8)
+    L += ADV
+    L += set_records("1")
+    e(f"s_add_u32 s{S_SLA}, s{S_WOFF}, 0x8000"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x18000")
+    L += dma_half("A", 0, 0) + dma_half("A", 1, 0) + dma_half("B", 0, 8) + dma_half("B", 1, 8)
+    return L
+
+
+def gen(TA, TB):
+    """The K loop of one output tile whose first two K-tiles have been requested (gen_pro) and whose K-tile 0 has LANDED (the
+    caller waits: the count depends on what it issued since).  Operands: %0 A lane address, %1 B lane address, %2 tr key,
+    %3..%18 LDS-DMA lane offsets, %19 A base, %20 B base, %21 A step, %22 B step, %23 nt, %24 wave LDS offset, %25 touch address
+    (64-bit per lane), %26 touch stride (64-bit), %27 touches, %28 K-tiles between touches - 1."""
+    L = descriptors(19, 20, 21, 22, 23, 24)
+    e = L.append
+    L += ADV + ADV                                                                 # descriptors point at K-tile 2
     if TA == 0:
         e(f"v_xor_b32 v{VA1}, 64, %0")
     else:
@@ -147,26 +186,13 @@ def gen(TA, TB):
     else:
         for j in range(8):
             e(f"v_xor_b32 v{VB + j}, {j}, %2"); e(f"v_lshl_add_u32 v{VB + j}, v{VB + j}, 5, %1")
-    for n in range(256):
-        e(f"v_accvgpr_write_b32 a{n}, 0")
-    adv = []
-    for rs, st in ((S_RA, S_STA), (S_RB, S_STB)):
-        adv += [f"s_add_u32 s{rs}, s{rs}, s{st}", f"s_addc_u32 s{rs + 1}, s{rs + 1}, s{st + 1}"]
-    # The loop is branch-free: a request for a K-tile past the last one goes through a descriptor with ZERO records (the range
-    # check drops it: no memory traffic, and it still counts in vmcnt), a fragment read past the last tile returns stale bytes
-    # nobody multiplies - so every wave issues the same instructions every trip and the waits are constants.
-    def set_records(tile_reg_or_imm):
-        return [f"s_cmp_lt_u32 {tile_reg_or_imm}, s{S_NT}", f"s_cselect_b32 s{S_TMP}, -1, 0",
-                f"s_mov_b32 s{S_RA + 2}, s{S_TMP}", f"s_mov_b32 s{S_RB + 2}, s{S_TMP}"]
-    # ---- prologue: K-tiles 0 and 1 (A stage 0 / 1, B stage 0 / 1), then fragments (0, ks0) -> P
-    e(f"s_mov_b32 s{S_SLA}, s{S_WOFF}"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x10000")
-    L += dma_half("A", 0, 3) + dma_half("A", 1, 3) + dma_half("B", 0, 11) + dma_half("B", 1, 11)
-    L += adv
-    L += set_records("1")
-    e(f"s_add_u32 s{S_SLA}, s{S_WOFF}, 0x8000"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x18000")
-    L += dma_half("A", 0, 3) + dma_half("A", 1, 3) + dma_half("B", 0, 11) + dma_half("B", 1, 11)
-    L += adv                                                                        # descriptors now point at K-tile 2
-    e("s_waitcnt vmcnt(16)"); e("s_barrier")
+    e(f"v_lshl_add_u64 v[{V_TADDR}:{V_TADDR + 1}], %25, 0, 0")
+    e(f"s_mov_b64 s[{S_TSTR}:{S_TSTR + 1}], %26"); e(f"s_mov_b32 s{S_TLEFT}, %27"); e(f"s_mov_b32 s{S_TPER}, %28"); e(f"s_mov_b32 s{S_TCD}, 0")
+    # (the accumulators were zeroed by CSM_W4_ZERO, before the caller's wait for K-tile 0)
+    # The loop is branch-free but for the touches: a request for a K-tile past the last one goes through a descriptor with ZERO
+    # records (the range check drops it: no memory traffic, and it still counts in vmcnt), a fragment read past the last tile
+    # returns stale bytes nobody multiplies - so every wave issues the same instructions every trip and the waits are constants.
+    e("s_barrier")
     e(f"s_mov_b32 s{S_T}, 0"); e(f"s_mov_b32 s{S_B3}, 0"); e(f"s_mov_b32 s{S_LA}, 0"); e(f"s_mov_b32 s{S_LB}, 0x10000")
     L += set_cur(TA, TB)
     L += frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
@@ -184,16 +210,26 @@ def gen(TA, TB):
     dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
     L += weave(mfmas(PA, PB), [(reads_q, 0, 44), (dmaB, 2, 64)])
     e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(8)"); e("s_barrier")
+    # ---- a touch (epilogue-read prefetch) every (s63 + 1) K-tiles while any are left: right after the barrier, so that the wait
+    # that has to let it pass (the next K-tile's) comes a whole K-tile later
+    e(f"s_sub_u32 s{S_TCD}, s{S_TCD}, 1"); e("s_cbranch_scc0 7f")
+    e(f"s_mov_b32 s{S_TCD}, s{S_TPER}")
+    e(f"s_cmp_eq_u32 s{S_TLEFT}, 0"); e("s_cbranch_scc1 7f")
+    e(f"s_sub_u32 s{S_TLEFT}, s{S_TLEFT}, 1")
+    e(f"global_load_dword v{V_JUNK}, v[{V_TADDR}:{V_TADDR + 1}], off")
+    e(f"v_lshl_add_u64 v[{V_TADDR}:{V_TADDR + 1}], s[{S_TSTR}:{S_TSTR + 1}], 0, v[{V_TADDR}:{V_TADDR + 1}]")
+    e("7:")
     # ---- ks1: fragments of (t+1, ks0) -> P and A(t+2) into the stage tile t just left
     e(f"s_add_u32 s{S_SLA}, s{S_LA}, s{S_WOFF}")                                     # A stage of tile t (free now) for the t+2 requests
     L += next_stage_offsets()
     reads_p = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
-    dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3) + adv
+    dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3) + ADV
     L += weave(mfmas(QA, QB), [(reads_p, 0, 44), (dmaA, 2, 64)])
     e("s_waitcnt lgkmcnt(0)")
     e(f"s_add_u32 s{S_T}, s{S_T}, 1"); e(f"s_cmp_lt_u32 s{S_T}, s{S_NT}"); e("s_cbranch_scc1 1b")
+    e("s_waitcnt vmcnt(0)")                                                        # (dropped requests, touches: nothing of mine stays in flight)
     e("s_nop 7"); e("s_nop 7"); e("s_nop 3")                                       # last MFMA results before v_accvgpr_read
-    return L
+    return [x for x in L if x is not None]
 
 
 def main(path):
@@ -207,8 +243,18 @@ def main(path):
                 for ins in body:
                     f.write(f'    "{ins}\\n\\t" \\\n')
                 f.write('    ""\n')
-        f.write("#define CSM_W4_CLOBBERS " + ", ".join([f'"v{n}"' for n in range(64, 230)] + [f'"a{n}"' for n in range(256)] +
-                                                      [f'"s{n}"' for n in range(40, 62)] + ['"scc"', '"vcc"', '"memory"']) + "\n")
+        f.write("#define CSM_W4_ZERO \\\n")
+        for n in range(256):
+            f.write(f'    "v_accvgpr_write_b32 a{n}, 0\\n\\t" \\\n')
+        f.write('    ""\n')
+        f.write("#define CSM_W4_ZERO_CLOBBERS " + ", ".join(f'"a{n}"' for n in range(256)) + "\n")
+        f.write("#define CSM_W4_PRO \\\n")
+        for ins in gen_pro():
+            f.write(f'    "{ins}\\n\\t" \\\n')
+        f.write('    ""\n')
+        f.write("#define CSM_W4_CLOBBERS " + ", ".join([f'"v{n}"' for n in range(64, 234)] + [f'"a{n}"' for n in range(256)] +
+                                                      [f'"s{n}"' for n in range(40, 68)] + ['"scc"', '"vcc"', '"memory"']) + "\n")
+        f.write("#define CSM_W4_PRO_CLOBBERS " + ", ".join([f'"s{n}"' for n in range(40, 62)] + ['"scc"', '"memory"']) + "\n")
 
 
 if __name__ == "__main__":
