@@ -805,3 +805,72 @@ def test_adamw_skipped_step_on_device(dev):
                 assert torch.equal(master, p0.float()) != moved
             assert torch.equal(p, p0) != moved and torch.equal(m, m0) != moved and torch.equal(v, v0) != moved
             assert float(grad.float().abs().max()) == 0.0, "zero_grad is honoured either way"
+
+
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_gemm_four_wave_kernel_equals_eight_wave(dev, mode):
+    """The four-wave 256x256 kernel (hand-scheduled inline-asm K loop, AGPR accumulators, 128x128 wave tiles: variant 4)
+    against the eight-wave one (variant 3): the same products in the same order, so the same bits - one to 16 K-tiles,
+    ragged edges, several tiles per persistent workgroup, bf16 and fp32 outputs, a residual that aliases the output - and
+    against the oracle's arithmetic."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(808)
+    for (M, N, K) in [(256, 256, 64), (256, 256, 128), (256, 512, 192), (304, 520, 448), (1000, 2112, 1024), (4096, 8192, 320), (8192, 2048, 4096)]:
+        if mode == "nt":
+            A, B, tA, tB = rnd((M, K), g), rnd((N, K), g), False, False
+        elif mode == "nn":
+            A, B, tA, tB = rnd((M, K), g), rnd((K, N), g), False, True
+        else:
+            A, B, tA, tB = rnd((K, M), g), rnd((K, N), g), True, True
+        Ad, Bd = A.to(dev), B.to(dev)
+        R = rnd((M, N), g).to(dev)
+        out = {}
+        try:
+            for v in (3, 4):
+                ops.lib.csm_set_gemm_variant(v)
+                C = torch.empty(M, N, dtype=BF, device=dev)
+                ops.gemm(Ad, Bd, C, None, tA, tB)
+                acc = R.clone()
+                ops.gemm(Ad, Bd, acc, acc, tA, tB, alpha=0.5)
+                C32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+                ops.gemm(Ad, Bd, C32, R, tA, tB, alpha=0.25)
+                out[v] = (C, acc, C32)
+        finally:
+            ops.lib.csm_set_gemm_variant(2)
+        for a, b in zip(out[3], out[4]):
+            assert torch.equal(a, b), f"{mode} {M}x{N}x{K}"
+        ref = (Ad.float().t() if tA else Ad.float()) @ (Bd.float() if tB else Bd.float().t())
+        close(f"w4 {mode} {M}x{N}x{K}", out[4][0], ref, 1e-2)
+        close(f"w4 {mode} f32+R", out[4][2], 0.25 * ref + R.float(), 2e-5 * math.sqrt(K))
+
+
+def test_gemm_four_wave_kernel_fused_epilogues(dev):
+    """The fused epilogues through the four-wave kernel - SwiGLU forward (gate/up + activation), SwiGLU backward (reads
+    gate/up, writes d gate/up), RoPE on the q|k columns of the fused projection - bit-equal to the eight-wave kernel's, over
+    several tiles per persistent workgroup and with one tile per workgroup."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(909)
+    M, F, D = 4096, 4096, 512
+    x, w13, w2 = rnd((M, D), g).to(dev), rnd((2 * F, D), g, 0.1).to(dev), rnd((D, F), g, 0.1).to(dev)
+    dout = rnd((M, D), g).to(dev)
+    S, H, KV, hd = 512, 8, 2, 64
+    wq = rnd(((H + 2 * KV) * hd, D), g, 0.1).to(dev)
+    table = O.rope_table(S, hd).to(dev).contiguous()
+    res = {}
+    try:
+        for key, (variant, persistent) in {"w8": (3, 1), "w4": (4, 1), "w4_one": (4, 0)}.items():
+            ops.lib.csm_set_gemm_variant(variant)
+            ops.lib.csm_set_gemm256_persistent(persistent)
+            gu, act = torch.empty(M, 2 * F, dtype=BF, device=dev), torch.empty(M, F, dtype=BF, device=dev)
+            ops.linear_swiglu_fwd(x, w13, gu, act)
+            dgu = torch.empty(M, 2 * F, dtype=BF, device=dev)
+            ops.linear_dx_swiglu_bwd(dout, w2, gu, dgu)
+            qkv = torch.empty(M, (H + 2 * KV) * hd, dtype=BF, device=dev)
+            ops.linear_rope_fwd(x, wq, qkv, table, S, (H + KV) * hd, hd)
+            res[key] = (gu, act, dgu, qkv)
+    finally:
+        ops.lib.csm_set_gemm_variant(2)
+        ops.lib.csm_set_gemm256_persistent(1)
+    for key in ("w4", "w4_one"):
+        for a, b in zip(res["w8"], res[key]):
+            assert torch.equal(a, b), key

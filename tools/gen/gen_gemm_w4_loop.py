@@ -133,7 +133,7 @@ for _rs, _st in ((S_RA, S_STA), (S_RB, S_STB)):
     ADV += [f"s_add_u32 s{_rs}, s{_rs}, s{_st}", f"s_addc_u32 s{_rs + 1}, s{_rs + 1}, s{_st + 1}"]
 
 # touch state (epilogue-read prefetch): s62 countdown, s63 period - 1, s64 touches left, s[66:67] byte stride; v230 junk, v[232:233] address
-S_TCD, S_TPER, S_TLEFT, S_TSTR = 62, 63, 64, 66
+S_TCD, S_TPER, S_TLEFT, S_TFLAG, S_TSTR = 62, 63, 64, 65, 66
 V_JUNK, V_TADDR = 230, 232
 
 
@@ -187,7 +187,7 @@ def gen(TA, TB):
         for j in range(8):
             e(f"v_xor_b32 v{VB + j}, {j}, %2"); e(f"v_lshl_add_u32 v{VB + j}, v{VB + j}, 5, %1")
     e(f"v_lshl_add_u64 v[{V_TADDR}:{V_TADDR + 1}], %25, 0, 0")
-    e(f"s_mov_b64 s[{S_TSTR}:{S_TSTR + 1}], %26"); e(f"s_mov_b32 s{S_TLEFT}, %27"); e(f"s_mov_b32 s{S_TPER}, %28"); e(f"s_mov_b32 s{S_TCD}, 0")
+    e(f"s_mov_b64 s[{S_TSTR}:{S_TSTR + 1}], %26"); e(f"s_mov_b32 s{S_TLEFT}, %27"); e(f"s_mov_b32 s{S_TPER}, %28"); e(f"s_mov_b32 s{S_TCD}, 0"); e(f"s_mov_b32 s{S_TFLAG}, 0")
     # (the accumulators were zeroed by CSM_W4_ZERO, before the caller's wait for K-tile 0)
     # The loop is branch-free but for the touches: a request for a K-tile past the last one goes through a descriptor with ZERO
     # records (the range check drops it: no memory traffic, and it still counts in vmcnt), a fragment read past the last tile
@@ -209,22 +209,30 @@ def gen(TA, TB):
     reads_q = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
     dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
     L += weave(mfmas(PA, PB), [(reads_q, 0, 44), (dmaB, 2, 64)])
-    e("s_waitcnt lgkmcnt(0)"); e("s_waitcnt vmcnt(8)"); e("s_barrier")
-    # ---- a touch (epilogue-read prefetch) every (s63 + 1) K-tiles while any are left: right after the barrier, so that the wait
-    # that has to let it pass (the next K-tile's) comes a whole K-tile later
-    e(f"s_sub_u32 s{S_TCD}, s{S_TCD}, 1"); e("s_cbranch_scc0 7f")
-    e(f"s_mov_b32 s{S_TCD}, s{S_TPER}")
-    e(f"s_cmp_eq_u32 s{S_TLEFT}, 0"); e("s_cbranch_scc1 7f")
-    e(f"s_sub_u32 s{S_TLEFT}, s{S_TLEFT}, 1")
-    e(f"global_load_dword v{V_JUNK}, v[{V_TADDR}:{V_TADDR + 1}], off")
-    e(f"v_lshl_add_u64 v[{V_TADDR}:{V_TADDR + 1}], s[{S_TSTR}:{S_TSTR + 1}], 0, v[{V_TADDR}:{V_TADDR + 1}]")
-    e("7:")
+    # my pieces of tile t+1 have landed: everything but the 8 B(t+2) requests of this phase - and, when the previous K-tile
+    # ended with a touch (s65), that touch, which is younger than every piece this wait is for
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_cmp_eq_u32 s{S_TFLAG}, 0"); e("s_cbranch_scc1 8f")
+    e("s_waitcnt vmcnt(9)"); e(f"s_mov_b32 s{S_TFLAG}, 0"); e("s_branch 9f")
+    e("8:"); e("s_waitcnt vmcnt(8)")
+    e("9:"); e("s_barrier")
     # ---- ks1: fragments of (t+1, ks0) -> P and A(t+2) into the stage tile t just left
     e(f"s_add_u32 s{S_SLA}, s{S_LA}, s{S_WOFF}")                                     # A stage of tile t (free now) for the t+2 requests
     L += next_stage_offsets()
     reads_p = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
     dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3) + ADV
     L += weave(mfmas(QA, QB), [(reads_p, 0, 44), (dmaA, 2, 64)])
+    # ---- a touch (epilogue-read prefetch) every (s63 + 1) K-tiles while any are left, AFTER this K-tile's last A request: it is
+    # then younger than everything the next K-tile's wait is for and stays in flight across it (vmcnt(9) there), i.e. it has
+    # two K-tiles to come back from HBM before a wait insists on it
+    e(f"s_sub_u32 s{S_TCD}, s{S_TCD}, 1"); e("s_cbranch_scc0 7f")
+    e(f"s_mov_b32 s{S_TCD}, s{S_TPER}")
+    e(f"s_cmp_eq_u32 s{S_TLEFT}, 0"); e("s_cbranch_scc1 7f")
+    e(f"s_sub_u32 s{S_TLEFT}, s{S_TLEFT}, 1")
+    e(f"global_load_dword v{V_JUNK}, v[{V_TADDR}:{V_TADDR + 1}], off")
+    e(f"v_lshl_add_u64 v[{V_TADDR}:{V_TADDR + 1}], s[{S_TSTR}:{S_TSTR + 1}], 0, v[{V_TADDR}:{V_TADDR + 1}]")
+    e(f"s_mov_b32 s{S_TFLAG}, 1")
+    e("7:")
     e("s_waitcnt lgkmcnt(0)")
     e(f"s_add_u32 s{S_T}, s{S_T}, 1"); e(f"s_cmp_lt_u32 s{S_T}, s{S_NT}"); e("s_cbranch_scc1 1b")
     e("s_waitcnt vmcnt(0)")                                                        # (dropped requests, touches: nothing of mine stays in flight)
