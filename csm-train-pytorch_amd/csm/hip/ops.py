@@ -174,7 +174,9 @@ def linear_dw(dy, x, out, accumulate=False, alpha=1.0):
     tiles128 = ((N + 127) // 128) * ((Kout + 127) // 128)
     # measured (tools/probes/wgrad_probe.py): once the 128x128 kernel has >= ~320 tiles for its 512 workgroup slots the
     # direct GEMM beats slabs + column sum (fused-qkv dW: 126 vs 160 us); below that the split wins (o_proj dW: 108 vs 132)
-    if tiles <= 96 and tiles128 < 320 and Mrows >= 4096 and out.is_contiguous() and Mrows % 64 == 0:
+    # (round 3, four-wave kernel: half a round of 256x256 tiles - the depth decoder's w2 gradient, 128 tiles - is better split in
+    # two than given to the 128x128 kernel: 261 vs 295 us)
+    if (tiles <= 96 and tiles128 < 320 or 96 < tiles <= 128) and Mrows >= 4096 and out.is_contiguous() and Mrows % 64 == 0:
         splits = 1
         while tiles * splits * 2 <= 256 and (Mrows // (splits * 2)) % 64 == 0 and Mrows // (splits * 2) >= 512:
             splits *= 2

@@ -236,7 +236,8 @@ int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int
                        hipStream_t stream, int epi_p0 = 0, int epi_p1 = 0, const void* xA = nullptr, const void* xB = nullptr, int kx = 0);
 
 int csm_gemm256w4_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
-                         int transA, int transB, int out_f32, float alpha, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
+                         int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB, long long sC,
+                         long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
                          hipStream_t stream, int epi_p0, int epi_p1);
 
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
@@ -299,9 +300,9 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, i
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     // variant 4: the four-wave 256x256 kernel with the hand-scheduled K loop (gemm256w4.hip), where it applies
     // (the four-wave kernel beats the 128x128 one from 1.5 rounds of tiles on: fused q|k|v forward, 384 tiles, 97 vs 115 us)
-    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch, 0.70)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && batch == 1 && kx == 0)
-        return csm_gemm256w4_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, epilogue, aux_in, aux_out,
-                                    ld_aux, stream, epi_p0, epi_p1);
+    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch, 0.70)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && kx == 0)
+        return csm_gemm256w4_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA, strideB,
+                                    strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant >= 3 && K % 64 == 0 && M >= 8 && N >= 8))
         return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
                                   strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1, xA, xB, kx);

@@ -24,7 +24,7 @@ for name, M, N, K in (("o_proj dW", 8192, 2048, 2048), ("qkv dW", 8192, 3072, 20
         ops.lib.csm_set_gemm_variant(v)
         res.append((f"direct v{v}", t(lambda: ops.gemm(dy, x, out, out, True, True))))
     ops.lib.csm_set_gemm_variant(2)
-    for splits in (2, 4, 8):
+    for splits in (2, 4, 8, 16):
         chunk = M // splits
         ws = torch.empty(splits, N * K, dtype=torch.float32, device=dev)
         def f():
