@@ -59,12 +59,14 @@ def dma_half(which, h, op_base):
     return out
 
 
-def mfmas(sa, sb):
+def mfmas(sa, sb, zero=False):
+    """64 MFMAs of one k-step; ``zero``: the accumulators START here (C = 0: the first k-step of an output tile)"""
     out = []
     for i in range(8):
         for j in range(8):
             c = (i * 8 + j) * 4
-            out.append(f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], v[{sb + 4 * j}:{sb + 4 * j + 3}], v[{sa + 4 * i}:{sa + 4 * i + 3}], a[{c}:{c + 3}]")
+            src_c = "0" if zero else f"a[{c}:{c + 3}]"
+            out.append(f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], v[{sb + 4 * j}:{sb + 4 * j + 3}], v[{sa + 4 * i}:{sa + 4 * i + 3}], {src_c}")
     return out
 
 
@@ -188,7 +190,7 @@ def gen(TA, TB):
             e(f"v_xor_b32 v{VB + j}, {j}, %2"); e(f"v_lshl_add_u32 v{VB + j}, v{VB + j}, 5, %1")
     e(f"v_lshl_add_u64 v[{V_TADDR}:{V_TADDR + 1}], %25, 0, 0")
     e(f"s_mov_b64 s[{S_TSTR}:{S_TSTR + 1}], %26"); e(f"s_mov_b32 s{S_TLEFT}, %27"); e(f"s_mov_b32 s{S_TPER}, %28"); e(f"s_mov_b32 s{S_TCD}, 0"); e(f"s_mov_b32 s{S_TFLAG}, 0")
-    # (the accumulators were zeroed by CSM_W4_ZERO, before the caller's wait for K-tile 0)
+    # (no zeroing of the 256 accumulators: the first k-step of the tile is a peeled copy of ks0 whose MFMAs take C = 0)
     # The loop is branch-free but for the touches: a request for a K-tile past the last one goes through a descriptor with ZERO
     # records (the range check drops it: no memory traffic, and it still counts in vmcnt), a fragment read past the last tile
     # returns stale bytes nobody multiplies - so every wave issues the same instructions every trip and the waits are constants.
@@ -197,18 +199,26 @@ def gen(TA, TB):
     L += set_cur(TA, TB)
     L += frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
     e("s_waitcnt lgkmcnt(0)")
+    def ks0(zero):
+        K0 = []
+        k = K0.append
+        k(f"s_add_u32 s{S_T2}, s{S_T}, 2")
+        K0 += set_records(f"s{S_T2}")
+        # B stage of tile t+2 = the stage tile t-1 used = (s58 + 2) % 3
+        k(f"s_add_u32 s{S_TMP}, s{S_B3}, 2"); k(f"s_cmp_ge_u32 s{S_TMP}, 3"); k(f"s_cselect_b32 s{S_SLB}, {-3 & 0xffffffff}, 0")
+        k(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_TMP}")
+        k(f"s_lshl_b32 s{S_SLB}, s{S_SLB}, 15"); k(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); k(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFF}")
+        # fragments (t, ks1) -> Q within the first 44 MFMAs, the 8 B(t+2) requests spread over all 64
+        reads_q = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
+        dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
+        return K0 + weave(mfmas(PA, PB, zero), [(reads_q, 0, 44), (dmaB, 2, 64)])
+    # ---- K-tile 0's first k-step, peeled: its MFMAs start the accumulators (C = 0); then into the loop at its mid-tile point
+    L += ks0(True)
+    e("s_branch 5f")
     # ---- the loop: one K-tile per trip
     e("1:")
-    e(f"s_add_u32 s{S_T2}, s{S_T}, 2")
-    L += set_records(f"s{S_T2}")
-    # B stage of tile t+2 = the stage tile t-1 used = (s58 + 2) % 3
-    e(f"s_add_u32 s{S_TMP}, s{S_B3}, 2"); e(f"s_cmp_ge_u32 s{S_TMP}, 3"); e(f"s_cselect_b32 s{S_SLB}, {-3 & 0xffffffff}, 0")
-    e(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_TMP}")
-    e(f"s_lshl_b32 s{S_SLB}, s{S_SLB}, 15"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); e(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFF}")
-    # ks0: fragments (t, ks1) -> Q within the first 44 MFMAs, the 8 B(t+2) requests spread over all 64
-    reads_q = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
-    dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
-    L += weave(mfmas(PA, PB), [(reads_q, 0, 44), (dmaB, 2, 64)])
+    L += ks0(False)
+    e("5:")
     # my pieces of tile t+1 have landed: everything but the 8 B(t+2) requests of this phase - and, when the previous K-tile
     # ended with a touch (s65), that touch, which is younger than every piece this wait is for
     e("s_waitcnt lgkmcnt(0)")
