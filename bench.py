@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048, help="positions of the CPU-baseline sample (SURVEY 8d protocol: B=1, S=2048)")
     ap.add_argument("--cpu-budget", type=float, default=340.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
+    ap.add_argument("--gemm-shapes", action="store_true", help="stderr: the instrumented step's GEMM launches grouped by shape")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (loss modes A / B, LoRA B=8, generate 10 s)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only; the number is not the metric)")
     ap.add_argument("--dry-run", action="store_true",
@@ -218,6 +219,19 @@ class GemmTimer:
             d[4][other] = d[4].get(other, 0) + 1
         return {k: {"tflops": v[0] / v[1] / 1e12, "time_ms": v[1] * 1e3, "launches": v[2], "avg_us": v[1] / v[2] * 1e6,
                     "flop": v[0], "operand_bytes_per_launch": v[3] / v[2], "split": v[4]} for k, v in agg.items() if v[1] > 0}
+
+
+    def print_shapes(self):
+        """stderr table of the instrumented step's launches grouped by (kind, FLOP, operand bytes, kernel): which shapes lose time."""
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flop, e0, e1, nbytes, kernel in self.records:
+            d = agg.setdefault((kind, flop, nbytes, kernel), [0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 1
+        for (kind, flop, nbytes, kernel), (sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print(f"{sec * 1e3:8.3f} ms  x{n:3d}  avg {sec / n * 1e6:7.1f} us  {flop / (sec / n) / 1e12:7.1f} TF/s  {flop / 1e9:7.1f} GF  "
+                  f"{nbytes / 1e6:7.1f} MB  {kind:14s} {kernel}", file=sys.stderr)
 
 
 def pmc_traffic(kernel):
@@ -493,6 +507,8 @@ def main():
         kinds, gemm_flop, att_flop = step_flops(model, res)
         # the dominant kernel = the kernel SYMBOL (as rocprofv3 prints it) with the most time in the instrumented step
         kernels = res["gt"].summary(by_kernel=True) if res["gt"] is not None else {}
+        if a.gemm_shapes and res["gt"] is not None and rank == 0:
+            res["gt"].print_shapes()
         dom = max(kernels.items(), key=lambda kv: kv[1]["time_ms"]) if kernels else (None, None)
         roof = None
         if dom[0] is not None:

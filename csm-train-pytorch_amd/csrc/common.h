@@ -19,8 +19,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return *reinterpret_cast<bf16_t*>(&b);
 }
 
+// two conversions in ONE v_cvt_pk_bf16_f32 (the scalar form above costs a conversion per value plus a shift and an or)
+typedef __attribute__((ext_vector_type(2))) float csm_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 csm_bf16x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const csm_f32x2 f = {lo, hi};
+    csm_bf16x2 b = __builtin_convertvector(f, csm_bf16x2);
+    return *reinterpret_cast<uint32_t*>(&b);
 }
 
 // sigmoid / SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (div_scale, rcp, 4 fma, div_fmas,
