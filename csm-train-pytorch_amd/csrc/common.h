@@ -19,10 +19,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return *reinterpret_cast<bf16_t*>(&b);
 }
 
-// two conversions in ONE v_cvt_pk_bf16_f32 (the scalar form above costs a conversion per value plus a shift and an or)
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// The same two conversions as ONE v_cvt_pk_bf16_f32 (the scalar form costs a conversion per value plus a shift and an or).
+// Identical values; kept separate because swapping it into every kernel shifts hipcc's fma-contraction choices around the
+// call sites, and the decode path and its prefix-recompute check (tests/test_configs_gpu.py) compare different kernels bit
+// for bit.  Used where the instruction count is exposed: the four-wave GEMM's epilogues.
 typedef __attribute__((ext_vector_type(2))) float csm_f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 csm_bf16x2;
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+__device__ __forceinline__ uint32_t pack2bf_pk(float lo, float hi) {
     const csm_f32x2 f = {lo, hi};
     csm_bf16x2 b = __builtin_convertvector(f, csm_bf16x2);
     return *reinterpret_cast<uint32_t*>(&b);
@@ -81,6 +88,11 @@ __device__ __forceinline__ void unpack8(const U4& u, float* f) {
 
 __device__ __forceinline__ U4 pack8(const float* f) {
     U4 u = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+    return u;
+}
+
+__device__ __forceinline__ U4 pack8_pk(const float* f) {
+    U4 u = {pack2bf_pk(f[0], f[1]), pack2bf_pk(f[2], f[3]), pack2bf_pk(f[4], f[5]), pack2bf_pk(f[6], f[7])};
     return u;
 }
 
