@@ -163,6 +163,18 @@ class GemmTimer:
             return ok
 
         ops.two_linear_dw = two_dw
+        self.orig_multi = ops.multi_linear_dw
+
+        def multi_dw(problems, accumulate=False, alpha=1.0):                    # several layers' attention weight gradients in one launch
+            e0, e1 = ev()
+            e0.record(); ok = timer.orig_multi(problems, accumulate=accumulate, alpha=alpha); e1.record()
+            if ok:
+                M = problems[0][0].shape[0]
+                fl = 2.0 * M * sum(p[2].numel() for p in problems)
+                timer.records.append(("tn_wgrad_bf16", fl, e0, e1, 2.0 * sum(t.numel() for p in problems for t in p), timer._kernel()))
+            return ok
+
+        ops.multi_linear_dw = multi_dw
         self.orig_kext = ops.gemm_kext
 
         def kext(A, B, C, xA, xB, R=None, transB=False, **kw):        # frozen projection + LoRA group in one product
@@ -192,6 +204,7 @@ class GemmTimer:
         self.ops.adamw_step = self.orig_adamw
         self.ops.adamw_step_split = self.orig_adamw_split
         self.ops.two_linear_dw = self.orig_two
+        self.ops.multi_linear_dw = self.orig_multi
         self.ops.gemm_kext = self.orig_kext
         self.ops.linear_rope_fwd = self.orig_rope
 

@@ -35,6 +35,9 @@ PAIR_DX_DW = int(_os.environ.get("CSM_PAIR_DX_DW", "0"))
 # A/B switch: the two small weight gradients of a layer (attention output projection: 64 tiles, fused q|k|v: 96 tiles of
 # 256x256) as ONE launch after the attention backward, instead of split-K slabs + column sum and a 128x128-tile launch
 GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
+# the attention projections' weight gradients of this many layers go out in one launch (1 = per layer); one layer's are 160
+# tiles of 256 x 256 - 0.63 of a round of the 256 CUs - three layers' 480: 1.9 rounds
+DEFER_ATTN_DW = int(_os.environ.get("CSM_DEFER_ATTN_DW", "3"))
 # LoRA groups ride on the frozen projections' GEMMs as K-extension operands (training/lora.py); 0 = per-adapter products
 LORA_FUSE = _os.environ.get("CSM_LORA_FUSE", "1") != "0"
 
@@ -184,9 +187,26 @@ class _Stack:
                 ops.colsum_bf16(parts, self.w(name, grad=True), accumulate=acc)
             return dx
 
+        pend = []        # deferred (dqkv, xn, dW_qkv, dh, o, dW_o, layer): the operands stay alive until their launch
+
+        def flush_attn_dw():
+            probs = []
+            for t in pend:
+                probs += [(t[0], t[1], t[2]), (t[3], t[4], t[5])]
+            if not (len(pend) > 1 and ops.multi_linear_dw(probs, accumulate=acc, alpha=alpha)):
+                for dq_, xn_, gq_, dh_, o_, go_, _ in pend:
+                    if not ops.two_linear_dw(dq_, xn_, gq_, dh_, o_, go_, accumulate=acc, alpha=alpha):
+                        ops.linear_dw(dh_, o_, go_, accumulate=acc, alpha=alpha)
+                        ops.linear_dw(dq_, xn_, gq_, accumulate=acc, alpha=alpha)
+            if on_layer_done is not None:
+                for t in pend:
+                    on_layer_done(self.prefix, t[6])
+            pend.clear()
+
         dx = norm_bwd(self.final["x"], "norm.scale", self.final["rstd"], dxf, None)
         for i in reversed(range(c.num_layers)):
             a = self.acts[i]
+            deferred = False
             hq, hk = H * hd, KV * hd
             # ---- MLP: out = h + w2(act)
             dgu = torch.empty(M, 2 * F, dtype=BF16, device=dev)
@@ -281,7 +301,11 @@ class _Stack:
                 if not (train_base and (PAIR_DX_DW & 8) and ops.linear_dx_dw(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn, a["xn"],
                                                                             self.w(f"layers.{i}.attn.qkv", True), accumulate=acc, alpha=alpha)):
                     ops.linear_dx(dqkv, self.w(f"layers.{i}.attn.qkv"), dxn)
-                    if train_base and group_dw and ops.two_linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), dh, a["o"],
+                    if train_base and group_dw and DEFER_ATTN_DW > 1:
+                        pend.append((dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), dh, a["o"],
+                                     self.w(f"layers.{i}.attn.output_proj.weight", True), i))
+                        deferred = True
+                    elif train_base and group_dw and ops.two_linear_dw(dqkv, a["xn"], self.w(f"layers.{i}.attn.qkv", True), dh, a["o"],
                                                                      self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha):
                         pass
                     elif train_base:
@@ -294,8 +318,14 @@ class _Stack:
                         ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
             dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh)
             self.acts[i] = None
-            if on_layer_done is not None:
+            if deferred:
+                # (layer 0 goes alone: what is launched last is what a data-parallel all-reduce cannot hide behind compute)
+                if len(pend) >= DEFER_ATTN_DW or i <= 1:
+                    flush_attn_dw()
+            elif on_layer_done is not None:
                 on_layer_done(self.prefix, i)
+        if pend:
+            flush_attn_dw()
         self.acts = []
         return dx
 

@@ -35,6 +35,7 @@ _SIGS = {
     "csm_skinny_nt_bf16": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p], _i),
     "csm_gemm_bf16_dgrad_wgrad": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _f, _p], _i),
     "csm_gemm_bf16_two_wgrad": ([_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p], _i),
+    "csm_gemm_bf16_multi_wgrad": ([_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p], _i),
     "csm_set_gemm_variant": ([_i], _i),
     "csm_set_gemm256_persistent": ([_i], _i),
     "csm_get_gemm256_persistent": ([], _i),

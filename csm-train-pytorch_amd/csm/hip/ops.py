@@ -158,6 +158,28 @@ def two_linear_dw(dy1, x1, dw1, dy2, x2, dw2, accumulate=False, alpha=1.0):
     return True
 
 
+def multi_linear_dw(problems, accumulate=False, alpha=1.0):
+    """dw_i[N_i,K_i] (+)= alpha dy_i^T x_i for a list of (dy_i, x_i, dw_i) sharing the row count M, in ONE launch of 256x256 tiles
+    (csm_gemm_bf16_multi_wgrad).  Returns False when the shapes do not suit it (caller falls back to its per-layer launches)."""
+    import ctypes as C
+    n = len(problems)
+    if n < 1 or n > 12:
+        return False
+    M = problems[0][0].shape[0]
+    for dy, x, dw in problems:
+        ts = (dy, x, dw)
+        if M % 64 or dy.shape[0] != M or x.shape[0] != M or any(t.stride(1) != 1 for t in ts) or any(d % 8 for t in ts for d in t.shape[1:]):
+            return False
+        assert dw.shape == (dy.shape[1], x.shape[1])
+    vp, ip = C.c_void_p * n, C.c_int * n
+    check(lib.csm_gemm_bf16_multi_wgrad(n, vp(*[p[0].data_ptr() for p in problems]), vp(*[p[1].data_ptr() for p in problems]),
+                                        vp(*[p[2].data_ptr() for p in problems]), ip(*[p[0].shape[1] for p in problems]),
+                                        ip(*[p[1].shape[1] for p in problems]), ip(*[p[0].stride(0) for p in problems]),
+                                        ip(*[p[1].stride(0) for p in problems]), ip(*[p[2].stride(0) for p in problems]),
+                                        M, int(accumulate), float(alpha), _stream()), "csm_gemm_bf16_multi_wgrad")
+    return True
+
+
 _splitk_ws = {}
 
 

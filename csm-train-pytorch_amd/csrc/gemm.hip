@@ -448,3 +448,31 @@ extern "C" int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW
     return csm_gemm256_two_wgrad_launch(dY1, X1, dW1, N1, K1, ld_dy1, ldx1, ld_dw1, dY2, X2, dW2, N2, K2, ld_dy2, ldx2, ld_dw2, M,
                                         accumulate, alpha, stream);
 }
+
+// n weight gradients dW_i[N_i][K_i] (+)= alpha dY_i[M][N_i]^T X_i[M][K_i] in ONE launch of 256 x 256 tiles (four-wave kernel): products
+// that each fill a fraction of a round of the 256 CUs (the attention projections' gradients of a layer: 160 tiles) fill whole
+// rounds together.  Every tile's arithmetic is that of csm_gemm_bf16_two_wgrad / csm_gemm_bf16 on the same product.
+int csm_gemm256w4_multi_wgrad_launch(int n, const void* const* dY, const void* const* X, void* const* dW, const int* N, const int* K,
+                                     const int* ld_dy, const int* ldx, const int* ld_dw, int M, int accumulate, float alpha,
+                                     hipStream_t stream);
+extern "C" int csm_gemm_bf16_multi_wgrad(int n, const void* const* dY, const void* const* X, void* const* dW, const int* N, const int* K,
+                                         const int* ld_dy, const int* ldx, const int* ld_dw, int M, int accumulate, float alpha,
+                                         hipStream_t stream) {
+    CSM_REQUIRE(n >= 1 && n <= 12 && dY && X && dW && N && K && ld_dy && ldx && ld_dw, "csm_gemm_bf16_multi_wgrad: 1..12 products, no null array");
+    CSM_REQUIRE(M > 0 && M % 64 == 0, "csm_gemm_bf16_multi_wgrad: M must be a positive multiple of 64");
+    for (int i = 0; i < n; ++i) {
+        CSM_REQUIRE(dY[i] && X[i] && dW[i], "csm_gemm_bf16_multi_wgrad: null operand in product %d", i);
+        CSM_REQUIRE(N[i] > 0 && K[i] > 0 && ((N[i] | K[i] | ld_dy[i] | ldx[i] | ld_dw[i]) & 7) == 0 && ld_dy[i] >= N[i] && ldx[i] >= K[i] &&
+                    ld_dw[i] >= K[i], "csm_gemm_bf16_multi_wgrad: product %d: dimensions must be multiples of 8, leading dimensions >= the row length", i);
+        CSM_REQUIRE((((uintptr_t)dY[i] | (uintptr_t)X[i] | (uintptr_t)dW[i]) & 15) == 0, "csm_gemm_bf16_multi_wgrad: product %d: operands must be 16-byte aligned", i);
+    }
+    if (!(g_gemm_w4 && g_gemm_variant != 3)) {        // kernel A/B switches: one product per launch through the ordinary dispatch
+        for (int i = 0; i < n; ++i) {
+            const int rc = csm_gemm_bf16(dY[i], X[i], dW[i], accumulate ? dW[i] : nullptr, N[i], K[i], M, ld_dy[i], ldx[i], ld_dw[i], ld_dw[i], 1, 1,
+                                         0, alpha, 1, 0, 0, 0, 0, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    return csm_gemm256w4_multi_wgrad_launch(n, dY, X, dW, N, K, ld_dy, ldx, ld_dw, M, accumulate, alpha, stream);
+}

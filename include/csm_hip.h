@@ -82,8 +82,13 @@ int csm_gemm_bf16_dgrad_wgrad(const void* dY, const void* W, void* dX, const voi
 int csm_gemm_bf16_two_wgrad(const void* dY1, const void* X1, void* dW1, int N1, int K1, int ld_dy1, int ldx1, int ld_dw1,
                             const void* dY2, const void* X2, void* dW2, int N2, int K2, int ld_dy2, int ldx2, int ld_dw2,
                             int M, int accumulate, float alpha, csm_stream_t stream);
-
-
+/* n (1..12) such weight gradients in one launch, arrays of n entries each.  The attention projections' gradients of one layer
+ * are 160 tiles of 256 x 256 - 0.63 of a round of the 256 CUs; the engine defers them and launches three layers' worth (480
+ * tiles, 1.9 rounds) together.  Tile arithmetic as csm_gemm_bf16_two_wgrad: results do not depend on the grouping.
+ * (autograd's per-Linear weight-gradient matmuls, reference src/csm/training/trainer.py:261-263) */
+int csm_gemm_bf16_multi_wgrad(int n, const void* const* dY, const void* const* X, void* const* dW, const int* N, const int* K,
+                              const int* ld_dy, const int* ldx, const int* ld_dw, int M, int accumulate, float alpha,
+                              csm_stream_t stream);
 
 
 /* tuning switch (A/B benchmarking): 0 register staging 128x128; 1 LDS-DMA 128x128; 2 auto = the 256x256 pipelined kernel

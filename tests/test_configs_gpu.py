@@ -85,6 +85,27 @@ def test_config2_full_param_b4_s2048(dev, csm1b):
         lib.csm_set_gemm256_persistent(1)
     assert (t3, s3, a3) == (t1, s1, a1), "one tile per workgroup vs persistent tile lists: loss bits"
     assert torch.equal(g3, g1), "one tile per workgroup vs persistent tile lists: gradient bits"
+    # the attention projections' weight gradients: three layers per launch (default) vs one layer per launch - the same tiles,
+    # so the same bits; and the per-layer "gradients are final" hook still fires exactly once per layer, layer 0 last
+    from csm import engine as E
+    assert E.DEFER_ATTN_DW == 3
+    seen = []
+    eng = m.engine
+    old_hook, old_defer = eng.grad_hook, E.DEFER_ATTN_DW
+    try:
+        eng.grad_hook = lambda prefix, i: seen.append((prefix, i))
+        t4, s4, a4, g4 = run(batch, rows4)
+        order3 = list(seen)
+        seen.clear()
+        E.DEFER_ATTN_DW = 1
+        t5, s5, a5, g5 = run(batch, rows4)
+        order1 = list(seen)
+    finally:
+        eng.grad_hook, E.DEFER_ATTN_DW = old_hook, old_defer
+    assert torch.equal(g4, g1) and torch.equal(g5, g1), "deferred attention weight gradients must not change a bit"
+    bb3 = [i for p_, i in order3 if p_ == "backbone"]
+    assert sorted(bb3) == list(range(16)) and bb3[-1] == 0 and sorted(order3) == sorted(order1)
+    assert [i for p_, i in order1 if p_ == "backbone"] == list(range(15, -1, -1))
 
 
 def test_config5_decode_kernels_at_csm1b_shapes_vs_oracle(dev):

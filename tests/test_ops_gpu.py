@@ -283,6 +283,43 @@ def test_two_linear_dw_grouped(dev, acc):
         close("grouped dW2", w2, 0.25 * dy2.float().t() @ x2.float(), 1e-2)
 
 
+@pytest.mark.parametrize("acc", [False, True])
+def test_multi_linear_dw_equals_separate_products(dev, acc):
+    """csm_gemm_bf16_multi_wgrad: six weight gradients (three layers' fused q|k|v and output projections, ragged shapes
+    included) in one launch = each product launched alone on the four-wave kernel, bit for bit; and with the four-wave kernel
+    switched off the entry point falls back to one ordinary launch per product."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(78)
+    M = 1024
+    shapes = [(768, 512), (512, 512), (776, 520), (264, 512), (768, 256), (512, 328)]
+    probs, refs = [], []
+    for n_, k_ in shapes:
+        dy, x, w = rnd((M, n_), g, 0.5).to(dev), rnd((M, k_), g, 0.5).to(dev), rnd((n_, k_), g, 0.1).to(dev)
+        r = w.clone()
+        ops.lib.csm_set_gemm_variant(4)
+        try:
+            ops.gemm(dy, x, r, r if acc else None, True, True, 0.25)
+        finally:
+            ops.lib.csm_set_gemm_variant(2)
+        probs.append((dy, x, w)); refs.append(r)
+    assert ops.multi_linear_dw(probs, accumulate=acc, alpha=0.25)
+    assert ops.lib.csm_gemm_last_kernel().decode() == "gemm256w4_multi_tn_kernel"
+    for (dy, x, w), r in zip(probs, refs):
+        assert torch.equal(w, r)
+        if not acc:
+            close("multi dW", w, 0.25 * dy.float().t() @ x.float(), 1e-2)
+    ops.lib.csm_set_gemm_tuning(1, 0)                    # four-wave kernel off: the same call, one product per launch
+    try:
+        outs = [(dy, x, torch.zeros_like(w)) for dy, x, w in probs]
+        assert ops.multi_linear_dw(outs, accumulate=False, alpha=0.25)
+        assert ops.lib.csm_gemm_last_kernel().decode() != "gemm256w4_multi_tn_kernel"
+        for (dy, x, w) in outs:
+            close("multi dW (fallback)", w, 0.25 * dy.float().t() @ x.float(), 1e-2)
+    finally:
+        ops.lib.csm_set_gemm_tuning(1, 1)
+    assert not ops.multi_linear_dw([(p[0][:1000], p[1][:1000], p[2]) for p in probs])     # M not a multiple of 64: caller falls back
+
+
 def test_adamw_split_master_is_bit_exact(dev):
     """csm_adamw_step_split (master = bf16 working copy + 16-bit lower half, 26 B/param) against csm_adamw_step (plain fp32
     master, 28 B/param): identical master, m and v bits after three steps with clipping; the working copy is the
