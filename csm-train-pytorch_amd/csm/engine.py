@@ -38,6 +38,8 @@ GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
 # the attention projections' weight gradients of this many layers go out in one launch (1 = per layer); one layer's are 160
 # tiles of 256 x 256 - 0.63 of a round of the 256 CUs - three layers' 480: 1.9 rounds
 DEFER_ATTN_DW = int(_os.environ.get("CSM_DEFER_ATTN_DW", "3"))
+# the RMSNorm scale gradients' column sums of a layer (and of the layers whose attention gradients are deferred) in one launch
+DEFER_NORM_DW = _os.environ.get("CSM_DEFER_NORM_DW", "1") == "1"
 # LoRA groups ride on the frozen projections' GEMMs as K-extension operands (training/lora.py); 0 = per-adapter products
 LORA_FUSE = _os.environ.get("CSM_LORA_FUSE", "1") != "0"
 
@@ -180,12 +182,24 @@ class _Stack:
         parts = torch.empty(nb, d, dtype=F32, device=dev) if train_base else None
         delta = torch.empty(2, B, H, S, dtype=F32, device=dev)   # attention-backward scratch (-delta, -lse log2e)
 
-        def norm_bwd(x, name, rstd, dy, dres):
+        pend_norm = []   # (per-block partial sums, scale gradient) of the layers' norms: reduced together, one launch per flush
+
+        def norm_bwd(x, name, rstd, dy, dres, defer=False):
             dx = torch.empty(M, d, dtype=BF16, device=dev)
+            if train_base and defer:
+                pp = torch.empty(nb, d, dtype=F32, device=dev)
+                ops.rmsnorm_bwd(x, self.w(name), rstd, dy, dx, dres, pp)
+                pend_norm.append((pp, self.w(name, grad=True)))
+                return dx
             ops.rmsnorm_bwd(x, self.w(name), rstd, dy, dx, dres, parts)
             if train_base:
                 ops.colsum_bf16(parts, self.w(name, grad=True), accumulate=acc)
             return dx
+
+        def flush_norms():
+            if pend_norm:
+                ops.colsum_bf16_multi(pend_norm, accumulate=acc)
+                pend_norm.clear()
 
         pend = []        # deferred (dqkv, xn, dW_qkv, dh, o, dW_o, layer): the operands stay alive until their launch
 
@@ -198,6 +212,7 @@ class _Stack:
                     if not ops.two_linear_dw(dq_, xn_, gq_, dh_, o_, go_, accumulate=acc, alpha=alpha):
                         ops.linear_dw(dh_, o_, go_, accumulate=acc, alpha=alpha)
                         ops.linear_dw(dq_, xn_, gq_, accumulate=acc, alpha=alpha)
+            flush_norms()
             if on_layer_done is not None:
                 for t in pend:
                     on_layer_done(self.prefix, t[6])
@@ -258,7 +273,7 @@ class _Stack:
                     if ad is not None:
                         ad.backward(a["hn"], dgu.view(M, F, 2)[:, :, col].contiguous(), a[f"t_{mod}"], dhn)
             del dgu
-            dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx)   # + residual path
+            dh = norm_bwd(a["h"], f"layers.{i}.mlp_norm.scale", a["rstd2"], dhn, dx, defer=DEFER_NORM_DW)   # + residual path
             # ---- attention: h = x + output_proj(o)
             do = torch.empty(M, H * hd, dtype=BF16, device=dev)
             group_dw = False
@@ -316,16 +331,21 @@ class _Stack:
                     ad = self._lora(i, mod)
                     if ad is not None:
                         ad.backward(a["xn"], dqkv[:, lo_:hi_], a[f"t_{mod}"], dxn)
-            dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh)
+            dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh, defer=DEFER_NORM_DW)
             self.acts[i] = None
             if deferred:
                 # (layer 0 goes alone: what is launched last is what a data-parallel all-reduce cannot hide behind compute)
                 if len(pend) >= DEFER_ATTN_DW or i <= 1:
                     flush_attn_dw()
-            elif on_layer_done is not None:
-                on_layer_done(self.prefix, i)
+            else:
+                if pend:
+                    flush_attn_dw()          # (mixed stacks: nothing of an earlier layer may stay pending behind this layer's hook)
+                flush_norms()                # this layer's two norms in one launch
+                if on_layer_done is not None:
+                    on_layer_done(self.prefix, i)
         if pend:
             flush_attn_dw()
+        flush_norms()
         self.acts = []
         return dx
 

@@ -46,6 +46,7 @@ _SIGS = {
     "csm_rmsnorm_bwd_blocks": ([], _i),
     "csm_rmsnorm_bwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _p], _i),
     "csm_colsum_bf16": ([_p, _i, _i, _p, _i, _p], _i),
+    "csm_colsum_bf16_multi": ([_i, _p, _p, _i, _i, _i, _p], _i),
     "csm_dropout_bf16": ([_p, _i, _p, _i, _ll, _i, _f, C.c_ulonglong, _i, _p], _i),
     "csm_bias_add_bf16": ([_p, _i, _p, _ll, _i, _p], _i),
     "csm_colsum_rows_bf16": ([_p, _i, _ll, _i, _p, _i, _p], _i),

@@ -233,6 +233,20 @@ def colsum_bf16(partials, dst, accumulate=False):
     check(lib.csm_colsum_bf16(partials.data_ptr(), rows, D, dst.data_ptr(), int(accumulate), _stream()), "csm_colsum_bf16")
 
 
+def colsum_bf16_multi(pairs, accumulate=False):
+    """dst_i (+)= column sums of partials_i for a list of (partials_i [rows, D] fp32, dst_i [D] bf16) of one shape: one launch per
+    8 pairs, the arithmetic of colsum_bf16 per pair."""
+    import ctypes as C
+    rows, D = pairs[0][0].shape
+    assert all(p.shape == (rows, D) and p.is_contiguous() and d.numel() == D for p, d in pairs)
+    for i in range(0, len(pairs), 8):
+        chunk = pairs[i:i + 8]
+        n = len(chunk)
+        vp = C.c_void_p * n
+        check(lib.csm_colsum_bf16_multi(n, vp(*[p.data_ptr() for p, _ in chunk]), vp(*[d.data_ptr() for _, d in chunk]), rows, D,
+                                        int(accumulate), _stream()), "csm_colsum_bf16_multi")
+
+
 def dropout_bf16(x, out, p, seed, accumulate=False):
     """out (+)= dropout(x, p) on [M, D] bf16 row-strided matrices; the mask depends only on (seed, row*D + col)."""
     M, D = x.shape

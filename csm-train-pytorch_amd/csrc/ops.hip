@@ -160,6 +160,36 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     }
 }
 
+// the same reduction for up to 8 (partials, dst) pairs of one shape in one launch (blockIdx.y = pair): the RMSNorm scale gradients
+// of the layers whose weight gradients the engine launches together
+struct ColsumMulti { const float* partials[8]; bf16_t* dst[8]; };
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumMulti p, int rows, int D, int accumulate) {
+    __shared__ float red[16][64];
+    const float* __restrict__ partials = p.partials[blockIdx.y];
+    bf16_t* __restrict__ dst = p.dst[blockIdx.y];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ns = blockDim.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (col < D) {
+        int r = sl;
+        for (; r + 3 * ns < rows; r += 4 * ns) {
+            t0 += partials[(size_t)r * D + col];
+            t1 += partials[(size_t)(r + ns) * D + col];
+            t2 += partials[(size_t)(r + 2 * ns) * D + col];
+            t3 += partials[(size_t)(r + 3 * ns) * D + col];
+        }
+        for (; r < rows; r += ns) t0 += partials[(size_t)r * D + col];
+    }
+    red[sl][c] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (sl == 0 && col < D) {
+        float t = 0.f;
+        for (int k = 0; k < ns; ++k) t += red[k][c];
+        if (accumulate) t += bf2f(dst[col]);
+        dst[col] = f2bf(t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LoRA side ops
 // Inverted dropout on a [M, D] bf16 matrix with row stride ld (reference lora.py:88-90, mlx nn.dropout: kept values are
 // scaled by 1/(1-p)).  The keep decision for element (row, col) is a pure function of (seed, row*D + col) - a
@@ -712,6 +742,19 @@ extern "C" int csm_colsum_bf16(const float* partials, int rows, int D, void* dst
     hipLaunchKernelGGL(colsum_kernel, dim3((D + 63) / 64), dim3(rows >= 64 ? 1024 : 256), 0, stream, partials, rows, D, (bf16_t*)dst,
                        accumulate);
     CSM_CHECK_LAUNCH("csm_colsum_bf16");
+    return 0;
+}
+
+extern "C" int csm_colsum_bf16_multi(int n, const float* const* partials, void* const* dst, int rows, int D, int accumulate,
+                                     hipStream_t stream) {
+    CSM_REQUIRE(n >= 1 && n <= 8 && partials && dst && rows > 0 && D > 0, "csm_colsum_bf16_multi: 1..8 pairs, rows, D > 0");
+    ColsumMulti p;
+    for (int i = 0; i < 8; ++i) {
+        CSM_REQUIRE(i >= n || (partials[i] && dst[i]), "csm_colsum_bf16_multi: null pointer in pair %d", i);
+        p.partials[i] = partials[i < n ? i : 0]; p.dst[i] = (bf16_t*)dst[i < n ? i : 0];
+    }
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((D + 63) / 64, n), dim3(rows >= 64 ? 1024 : 256), 0, stream, p, rows, D, accumulate);
+    CSM_CHECK_LAUNCH("csm_colsum_bf16_multi");
     return 0;
 }
 

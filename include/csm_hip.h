@@ -113,6 +113,9 @@ int csm_rmsnorm_bwd_blocks(void);
 int csm_rmsnorm_bwd(const void* x, const void* scale, const float* rstd, const void* dy, const void* dres, void* dx,
                     float* dscale_partials /* [csm_rmsnorm_bwd_blocks()][D] or NULL */, int M, int D, csm_stream_t stream);
 int csm_colsum_bf16(const float* partials, int rows, int D, void* dst, int accumulate, csm_stream_t stream);
+/* the same reduction for n (1..8) pairs of one shape in one launch (the RMSNorm scale gradients of the layers whose small weight
+ * gradients the engine launches together); per column the arithmetic of csm_colsum_bf16 */
+int csm_colsum_bf16_multi(int n, const float* const* partials, void* const* dst, int rows, int D, int accumulate, csm_stream_t stream);
 
 /* ---- LoRA side ops (reference mlx/components/lora.py:85-102): inverted dropout of the adapter input (mask is a pure
  * function of (seed, row*D+col), so the backward regenerates it; accumulate=1: out += dropout(in)), the optional

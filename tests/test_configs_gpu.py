@@ -100,9 +100,12 @@ def test_config2_full_param_b4_s2048(dev, csm1b):
         E.DEFER_ATTN_DW = 1
         t5, s5, a5, g5 = run(batch, rows4)
         order1 = list(seen)
+        E.DEFER_NORM_DW = False              # RMSNorm scale gradients: one column-sum launch per norm instead of per group
+        t6, s6, a6, g6 = run(batch, rows4)
     finally:
-        eng.grad_hook, E.DEFER_ATTN_DW = old_hook, old_defer
+        eng.grad_hook, E.DEFER_ATTN_DW, E.DEFER_NORM_DW = old_hook, old_defer, True
     assert torch.equal(g4, g1) and torch.equal(g5, g1), "deferred attention weight gradients must not change a bit"
+    assert torch.equal(g6, g1), "grouped RMSNorm scale-gradient reductions must not change a bit"
     bb3 = [i for p_, i in order3 if p_ == "backbone"]
     assert sorted(bb3) == list(range(16)) and bb3[-1] == 0 and sorted(order3) == sorted(order1)
     assert [i for p_, i in order1 if p_ == "backbone"] == list(range(15, -1, -1))

@@ -284,6 +284,26 @@ def test_two_linear_dw_grouped(dev, acc):
 
 
 @pytest.mark.parametrize("acc", [False, True])
+def test_colsum_multi_equals_single(dev, acc):
+    """csm_colsum_bf16_multi (11 pairs = two launches of <= 8) against csm_colsum_bf16 per pair: the same bits."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(5)
+    rows, D = 256, 2048
+    pairs, refs = [], []
+    for _ in range(11):
+        p_ = torch.randn(rows, D, generator=g).to(dev)
+        d0 = rnd((D,), g, 0.3).to(dev)
+        r = d0.clone()
+        ops.colsum_bf16(p_, r, accumulate=acc)
+        pairs.append((p_, d0)); refs.append(r)
+    ops.colsum_bf16_multi(pairs, accumulate=acc)
+    for (p_, d0), r in zip(pairs, refs):
+        assert torch.equal(d0, r)
+    if not acc:
+        close("colsum", pairs[0][1], pairs[0][0].sum(0), 1e-2)
+
+
+@pytest.mark.parametrize("acc", [False, True])
 def test_multi_linear_dw_equals_separate_products(dev, acc):
     """csm_gemm_bf16_multi_wgrad: six weight gradients (three layers' fused q|k|v and output projections, ragged shapes
     included) in one launch = each product launched alone on the four-wave kernel, bit for bit; and with the four-wave kernel
