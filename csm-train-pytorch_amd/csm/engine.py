@@ -202,16 +202,31 @@ class _Stack:
                 pend_norm.clear()
 
         pend = []        # deferred (dqkv, xn, dW_qkv, dh, o, dW_o, layer): the operands stay alive until their launch
+        # A narrow stack (the depth decoder, d = 1024): every weight gradient but w13's is a fraction of a round of 256 x 256
+        # tiles (o_proj 16, q|k|v 24, w2 128) and would go through fp32 split-K slabs + a column-sum launch each.  Deferred to
+        # the end of the stack they are one launch of 160 tiles (attention, all layers) and one of 256 per two layers (w2).
+        small = (train_base and DEFER_ATTN_DW > 1 and GROUP_ATTN_DW and not PAIR_DX_DW and c.embed_dim < 2048 and M % 64 == 0
+                 and M >= 4096)
+        pend_w2 = []     # (dy, act, dW_w2) of a narrow stack
+
+        def flush_w2():
+            if pend_w2 and not (len(pend_w2) > 1 and ops.multi_linear_dw(pend_w2, accumulate=acc, alpha=alpha)):
+                for dy_, x_, g_ in pend_w2:
+                    ops.linear_dw(dy_, x_, g_, accumulate=acc, alpha=alpha)
+            pend_w2.clear()
 
         def flush_attn_dw():
-            probs = []
-            for t in pend:
-                probs += [(t[0], t[1], t[2]), (t[3], t[4], t[5])]
-            if not (len(pend) > 1 and ops.multi_linear_dw(probs, accumulate=acc, alpha=alpha)):
-                for dq_, xn_, gq_, dh_, o_, go_, _ in pend:
-                    if not ops.two_linear_dw(dq_, xn_, gq_, dh_, o_, go_, accumulate=acc, alpha=alpha):
-                        ops.linear_dw(dh_, o_, go_, accumulate=acc, alpha=alpha)
-                        ops.linear_dw(dq_, xn_, gq_, accumulate=acc, alpha=alpha)
+            for c0 in range(0, len(pend), 6):                # at most 12 products per launch
+                chunk = pend[c0:c0 + 6]
+                probs = []
+                for t in chunk:
+                    probs += [(t[0], t[1], t[2]), (t[3], t[4], t[5])]
+                if not (len(chunk) > 1 and ops.multi_linear_dw(probs, accumulate=acc, alpha=alpha)):
+                    for dq_, xn_, gq_, dh_, o_, go_, _ in chunk:
+                        if not ops.two_linear_dw(dq_, xn_, gq_, dh_, o_, go_, accumulate=acc, alpha=alpha):
+                            ops.linear_dw(dh_, o_, go_, accumulate=acc, alpha=alpha)
+                            ops.linear_dw(dq_, xn_, gq_, accumulate=acc, alpha=alpha)
+            flush_w2()
             flush_norms()
             if on_layer_done is not None:
                 for t in pend:
@@ -253,7 +268,12 @@ class _Stack:
                 ops.swiglu_bwd(a["gu"], dact, dgu)
                 del dact
             if train_base and not w2_done:
-                ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=acc, alpha=alpha)
+                if small:
+                    pend_w2.append((dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True)))
+                    if len(pend_w2) == 2:
+                        flush_w2()
+                else:
+                    ops.linear_dw(dx, a["act"], self.w(f"layers.{i}.mlp.w2.weight", True), accumulate=acc, alpha=alpha)
             dhn = torch.empty(M, d, dtype=BF16, device=dev)
             G, fused = self._group(i, "mlp_in")
             fused = fused and "tx_mlp_in" in a
@@ -290,7 +310,7 @@ class _Stack:
                                                                             accumulate=acc, alpha=alpha)):
                     ops.linear_dx(dh, self.w(f"layers.{i}.attn.output_proj.weight"), do)
                     # (the output projection's dW waits for the q|k|v projection's below when the two can share one launch)
-                    group_dw = train_base and GROUP_ATTN_DW and not (PAIR_DX_DW & 8) and M % 64 == 0 and M >= 4096 and c.embed_dim >= 2048
+                    group_dw = train_base and GROUP_ATTN_DW and not (PAIR_DX_DW & 8) and M % 64 == 0 and M >= 4096 and (c.embed_dim >= 2048 or small)
                     if train_base and not group_dw:
                         ops.linear_dw(dh, a["o"], self.w(f"layers.{i}.attn.output_proj.weight", True), accumulate=acc, alpha=alpha)
                 ad = self._lora(i, "output_proj")
@@ -334,16 +354,17 @@ class _Stack:
             dx = norm_bwd(a["x"], f"layers.{i}.sa_norm.scale", a["rstd1"], dxn, dh, defer=DEFER_NORM_DW)
             self.acts[i] = None
             if deferred:
-                # (layer 0 goes alone: what is launched last is what a data-parallel all-reduce cannot hide behind compute)
-                if len(pend) >= DEFER_ATTN_DW or i <= 1:
+                # (layer 0 goes alone: what is launched last is what a data-parallel all-reduce cannot hide behind compute;
+                #  a narrow stack keeps everything to its end - the wide stack's backward follows and hides its all-reduce)
+                if not small and (len(pend) >= DEFER_ATTN_DW or i <= 1):
                     flush_attn_dw()
             else:
-                if pend:
+                if pend or pend_w2:
                     flush_attn_dw()          # (mixed stacks: nothing of an earlier layer may stay pending behind this layer's hook)
                 flush_norms()                # this layer's two norms in one launch
                 if on_layer_done is not None:
                     on_layer_done(self.prefix, i)
-        if pend:
+        if pend or pend_w2:
             flush_attn_dw()
         flush_norms()
         self.acts = []
