@@ -103,6 +103,8 @@ if os.environ.get("CSM_GEMM_W4") == "0":                # kernel A/B only (tools
     lib.csm_set_gemm_tuning(1, 0)
 if os.environ.get("CSM_GEMM_FAST_EPI") == "0":          # kernel A/B only (tools/probes)
     lib.csm_set_gemm_tuning(6, 0)
+if os.environ.get("CSM_GEMM_W4_KEXT") == "0":           # kernel A/B only: K-extension (LoRA) products on the eight-wave kernel
+    lib.csm_set_gemm_tuning(7, 0)
 if os.environ.get("CSM_GEMM_STAGGER"):                  # "groups,fwd,bwd,other" (10 ns ticks): kernel A/B only (tools/probes)
     for _k, _v in enumerate(os.environ["CSM_GEMM_STAGGER"].split(",")):
         lib.csm_set_gemm_tuning(2 + _k, int(_v))

@@ -238,11 +238,12 @@ int csm_gemm256_launch(const void* A, const void* B, void* C, const void* R, int
 int csm_gemm256w4_launch(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
                          int transA, int transB, int out_f32, float alpha, int batch, long long sA, long long sB, long long sC,
                          long long sR, int epi_mode, const void* aux_in, void* aux_out, int ld_aux,
-                         hipStream_t stream, int epi_p0, int epi_p1);
+                         hipStream_t stream, int epi_p0, int epi_p1, const void* xA = nullptr, const void* xB = nullptr, int kx = 0);
 
 // 256x256 tiles run one workgroup per CU: use them when the tile count fills (most of) a whole number of rounds over
 // the 256 CUs and little of the tile area hangs over the matrix edge.
 int g_gemm_w4 = 1;     // csm_set_gemm_tuning(1, v)
+int g_w4_kext = 1;     // csm_set_gemm_tuning(7, v): K-extension products on the four-wave kernel
 static bool prefer_256(int M, int N, int K, int batch, double need = 0.80) {
     if (K % 64 != 0 || M < 8 || N < 8) return false;
     const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
@@ -266,10 +267,11 @@ extern int g_gemm_touch;
 extern int g_w4_stagger[4];
 extern int g_w4_fast_epi;
 extern "C" int csm_set_gemm_tuning(int key, int value) {
-    CSM_REQUIRE(key >= 0 && key <= 6, "csm_set_gemm_tuning: unknown key %d", key);
+    CSM_REQUIRE(key >= 0 && key <= 7, "csm_set_gemm_tuning: unknown key %d", key);
     if (key == 0) g_gemm_touch = value ? 1 : 0;
     else if (key == 1) g_gemm_w4 = value ? 1 : 0;
     else if (key == 6) g_w4_fast_epi = value ? 1 : 0;
+    else if (key == 7) g_w4_kext = value ? 1 : 0;
     else {      // 2: number of start groups of a persistent four-wave launch; 3 / 4 / 5: offset between groups in 10 ns ticks
         CSM_REQUIRE(value >= 0 && value <= (key == 2 ? 32 : 20000), "csm_set_gemm_tuning: key %d value %d out of range", key, value);
         g_w4_stagger[key - 2] = key == 2 ? (value < 1 ? 1 : value) : value;
@@ -307,9 +309,9 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* R, i
     CSM_REQUIRE(epilogue >= 0 && epilogue <= 3, "csm_gemm_bf16_ex: unknown epilogue %d", epilogue);
     // variant 4: the four-wave 256x256 kernel with the hand-scheduled K loop (gemm256w4.hip), where it applies
     // (the four-wave kernel beats the 128x128 one from 1.5 rounds of tiles on: fused q|k|v forward, 384 tiles, 97 vs 115 us)
-    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch, 0.70)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && kx == 0)
+    if (((g_gemm_variant == 2 && g_gemm_w4 && prefer_256(M, N, K, batch, 0.70)) || (g_gemm_variant == 4 && K % 64 == 0 && M >= 8 && N >= 8)) && (kx == 0 || g_w4_kext))
         return csm_gemm256w4_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA, strideB,
-                                    strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1);
+                                    strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1, xA, xB, kx);
     if ((g_gemm_variant == 2 && prefer_256(M, N, K, batch)) || (g_gemm_variant >= 3 && K % 64 == 0 && M >= 8 && N >= 8))
         return csm_gemm256_launch(A, B, C, R, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_f32, alpha, batch, strideA,
                                   strideB, strideC, strideR, epilogue, aux_in, aux_out, ld_aux, stream, epi_p0, epi_p1, xA, xB, kx);

@@ -477,6 +477,35 @@ def test_gemm_k_extension(dev, M, N, K, kx, transB, epi):
         assert torch.equal(z, plain)
 
 
+@pytest.mark.parametrize("M,N,K,kx,transB", [(1024, 768, 256, 32, False), (520, 1000, 192, 64, True), (2048, 4096, 512, 96, False)])
+def test_gemm_k_extension_four_wave_equals_eight_wave(dev, M, N, K, kx, transB):
+    """The K-extension on the four-wave 256x256 kernel (the extension's k-steps as one more asm block on the asm-owned
+    accumulators) against the eight-wave kernel's: the same MFMA sequence per accumulator, so the same bits - with and
+    without a residual, ragged edges included."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(M + 3 * N + kx)
+    a = rnd((M, K), g, 0.5).to(dev)
+    b = rnd((K, N) if transB else (N, K), g, 0.1).to(dev)
+    xa, xb = rnd((M, kx), g, 0.5).to(dev), rnd((N, kx), g, 0.2).to(dev)
+    res = rnd((M, N), g, 1.0).to(dev)
+    outs = {}
+    for variant in (3, 4):
+        ops.lib.csm_set_gemm_variant(variant)
+        try:
+            for with_r in (False, True):
+                o = torch.empty(M, N, dtype=BF, device=dev)
+                ops.gemm_kext(a, b, o, xa, xb, R=res if with_r else None, transB=transB)
+                want = "gemm256w4_kernel" if variant == 4 else "gemm256p_kernel"
+                assert ops.lib.csm_gemm_last_kernel().decode().startswith(want), ops.lib.csm_gemm_last_kernel()
+                outs[(variant, with_r)] = o
+        finally:
+            ops.lib.csm_set_gemm_variant(2)
+    for with_r in (False, True):
+        assert torch.equal(outs[(3, with_r)], outs[(4, with_r)])
+    y = a.float() @ (b.float() if transB else b.float().t()) + xa.float() @ xb.float().t()
+    close("k-extension (four-wave)", outs[(4, False)], y, 1e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(16384, 32, 2048), (4096, 64, 3072), (100, 32, 384), (33, 64, 128), (50, 32, 192)])
 def test_skinny_nt(dev, M, N, K):
     """csm_skinny_nt_bf16: out = alpha x wt^T for a LoRA group's ranks, against fp32 (ragged M, K halves that are not a

@@ -270,6 +270,15 @@ def main(path):
         for ins in gen_pro():
             f.write(f'    "{ins}\\n\\t" \\\n')
         f.write('    ""\n')
+        # one 32-deep k-step whose fragments arrive as operands (K-extension: a LoRA group's columns after the main loop):
+        # %0..%7 the wave's 8 A-row fragments, %8..%15 its 8 B-row fragments
+        f.write("#define CSM_W4_KEXT \\\n")
+        for i in range(8):
+            for j in range(8):
+                c = (i * 8 + j) * 4
+                f.write(f'    "v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], %{8 + j}, %{i}, a[{c}:{c + 3}]\\n\\t" \\\n')
+        f.write('    "s_nop 7\\n\\ts_nop 7\\n\\t" \\\n    ""\n')
+        f.write("#define CSM_W4_KEXT_CLOBBERS " + ", ".join(f'"a{n}"' for n in range(256)) + "\n")
         f.write("#define CSM_W4_CLOBBERS " + ", ".join([f'"v{n}"' for n in range(64, 234)] + [f'"a{n}"' for n in range(256)] +
                                                       [f'"s{n}"' for n in range(40, 68)] + ['"scc"', '"vcc"', '"memory"']) + "\n")
         f.write("#define CSM_W4_PRO_CLOBBERS " + ", ".join([f'"s{n}"' for n in range(40, 62)] + ['"scc"', '"memory"']) + "\n")
