@@ -360,17 +360,21 @@ class Model(nn.Module):
                 raise RuntimeError(f"load_state_dict: shape mismatch for {k}: {tuple(v.shape)} vs {tuple(dst.shape)}")
             dst.copy_(v.to(device=dst.device, dtype=dst.dtype))
         self._fp32_source = {k: v for k, v in state_dict.items() if torch.is_tensor(v) and v.dtype == torch.float32} or None
-        self.params_rewritten(base=any(k in views for k in state_dict), lora=any(k in lora_names for k in state_dict))
+        self.params_rewritten(base=any(k in views for k in state_dict), lora=any(k in lora_names for k in state_dict),
+                              from_fp32_source=True)
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
-    def params_rewritten(self, base: bool = True, lora: bool = True):
+    def params_rewritten(self, base: bool = True, lora: bool = True, from_fp32_source: bool = False):
         """Tell every live optimiser built on this model that the working weights changed underneath it (its fp32 master
-        is partly stored IN the bf16 arena: training/optim.py)."""
+        is partly stored IN the bf16 arena: training/optim.py).  Any rewrite that is not ``load_state_dict`` itself also
+        retires the fp32 state dict kept from the last load - it no longer describes the weights."""
+        if not from_fp32_source and base:
+            self._fp32_source = None
         alive = []
         for ref in getattr(self, "_optimizers", []):
             opt = ref()
             if opt is not None:
-                opt.params_rewritten(base, lora)
+                opt.params_rewritten(base, lora, from_fp32_source)
                 alive.append(ref)
         if hasattr(self, "_optimizers"):
             self._optimizers = alive

@@ -111,9 +111,13 @@ class GradSync:
             t = slots["text_embeddings.weight"]
             buckets[("embeddings", -1)] = [sl for sl in buckets[("embeddings", -1)] if sl != (t.offset, t.numel)]
             cap = int(os.environ.get("CSM_DP_TEXT_ROWS_CAP", cls.TEXT_ROWS_CAP))
+            # ``host``: a ring of pinned int32 slots, allocated ONCE (a pinned allocation is a driver call that can serialise with
+            # in-flight work; it must not happen inside the overlap window of every step).  Step k writes slot k % len; the
+            # host has read step k - OVERFLOW_LAG's slot before step k launches (arm), so OVERFLOW_LAG + 2 slots never collide.
             sparse = dict(slice=(t.offset, t.numel), D=model.bb.embed_dim, seen=[], cap=cap, n_rows=t.shape[0],
                           overflow=torch.zeros(1, dtype=torch.int32, device=model.grad_arena.device),
-                          pending=[])      # (optimiser step, event, pinned int32[1]) per exchange, oldest first
+                          host=torch.zeros(cls.OVERFLOW_LAG + 2, dtype=torch.int32).pin_memory(),
+                          pending=[])      # (optimiser step, event, slot of ``host``) per exchange, oldest first
         merged = {k: cls._merge(v) for k, v in buckets.items()}
         extra = [model.lora.grad_arena] if model.lora is not None else []
         gs = cls(model.grad_arena, merged, group, extra)
@@ -197,9 +201,9 @@ class GradSync:
         if sp is None:
             return
         while sp["pending"] and (block or sp["pending"][0][0] <= self.opt_step - self.OVERFLOW_LAG):
-            step, event, host = sp["pending"].pop(0)
+            step, event, slot = sp["pending"].pop(0)
             event.synchronize()
-            if int(host[0]) > 0:
+            if int(sp["host"][slot]) > 0:
                 self._on_overflow(step)
 
     def _on_overflow(self, step: int):
@@ -232,6 +236,10 @@ class GradSync:
             dev = g.device
             send_r = torch.full((cap + 1,), -1, dtype=torch.int32, device=dev)
             if sp["seen"]:
+                for t in sp["seen"]:
+                    # allocated on the compute stream, consumed here on the communication stream and dropped below: without
+                    # this the caching allocator may hand the block to the next compute-stream allocation before the sort ran
+                    t.record_stream(self.comm_stream)
                 ids = torch.cat(sp["seen"]).sort().values                       # sentinel n_rows sorts last
                 first = torch.ones_like(ids, dtype=torch.bool)
                 first[1:] = ids[1:] != ids[:-1]
@@ -253,11 +261,13 @@ class GradSync:
             for r in range(self.world_size):                                     # fixed order: every rank computes the same bits
                 ops.rows_add_bf16(g, all_r[r * cap:(r + 1) * cap], all_g[r * cap:(r + 1) * cap], 1)
             dist.all_reduce(sp["overflow"], op=dist.ReduceOp.MAX, group=self.group)
-            host = torch.zeros(1, dtype=torch.int32).pin_memory()               # this step's own slot: nothing overwrites it
-            host.copy_(sp["overflow"], non_blocking=True)
+            slot = self.opt_step % sp["host"].numel()                            # this step's own slot of the pinned ring
+            if any(s_ == slot for _, _, s_ in sp["pending"]):                   # (cannot happen with arm() before every step)
+                self.check_overflow(block=True)
+            sp["host"][slot:slot + 1].copy_(sp["overflow"], non_blocking=True)
             event = torch.cuda.Event()
             event.record()
-            sp["pending"].append((self.opt_step, event, host))
+            sp["pending"].append((self.opt_step, event, slot))
 
     def _all_gather(self, out: torch.Tensor, part: torch.Tensor):
         """out = concatenation over the ranks of ``part`` (one flat collective on RCCL; the list form where the backend -

@@ -93,7 +93,12 @@ class CSMLoRATrainer:
         self.optimizer = FusedAdamW(self.model, {}, lora_lr=self.learning_rate, lora_weight_decay=0.0)
         base = sum(self.model.group_range(g)[1] for g in ("backbone", "decoder"))
         self.logger.info(f"Training with {n:,} LoRA parameters ({100.0 * n / base:.3f}% of the transformer stacks)")
-        self.grad_sync = GradSync.for_model(self.model) if GradSync.active() else None
+        self._ensure_grad_sync()
+
+    def _ensure_grad_sync(self):
+        """(Re-)attach the gradient exchange; ``train`` closes it when it returns (GradSync.close)."""
+        if self.grad_sync is None and GradSync.active():
+            self.grad_sync = GradSync.for_model(self.model)
 
     def train_step(self, batch):
         """Reference lora_trainer.py:374-457: loss + grads w.r.t. LoRA params -> optional clip -> Adam.  Returns the
@@ -119,6 +124,7 @@ class CSMLoRATrainer:
          and checkpoints are written."""
         if self.optimizer is None:
             self.prepare_optimizer()
+        self._ensure_grad_sync()
         self.max_grad_norm = max_grad_norm
         if resume_from:
             self.load_lora_weights(resume_from)
@@ -161,6 +167,9 @@ class CSMLoRATrainer:
             self.epoch = epoch + 1
         if rank == 0:
             self.logger.info("Training completed")
+        if self.grad_sync is not None:
+            self.grad_sync.close()       # gives the process-global GEMM schedule switch back (a later train() re-attaches)
+            self.grad_sync = None
         return self.best_loss
 
     def _validate(self, val_dataset, batch_size: int) -> float:

@@ -57,7 +57,7 @@ class FusedAdamW:
             self.param_groups.append(dict(name="lora", lr=float(lora_lr), weight_decay=lora_weight_decay, offset=0,
                                           numel=lo.arena.numel(), param=lo.arena, grad=lo.grad_arena))
         for g in self.param_groups:
-            master = self._seed_master(g)
+            master = self._seed_master(g, from_fp32_source=True)
             if SPLIT_MASTER:
                 lo = split_master(master, g["param"])  # the working copy becomes the master's (half-up rounded) upper half
                 self.state[g["name"]] = dict(lo=lo, m=torch.zeros_like(master), v=torch.zeros_like(master))
@@ -72,12 +72,14 @@ class FusedAdamW:
             model._optimizers = []
         model._optimizers.append(weakref.ref(self))
 
-    def _seed_master(self, g) -> torch.Tensor:
-        """fp32 master of a group from the current bf16 working weights; a state dict loaded in fp32 (``Model._fp32_source``)
-        seeds its parameters at full precision."""
+    def _seed_master(self, g, from_fp32_source: bool = False) -> torch.Tensor:
+        """fp32 master of a group from the current bf16 working weights.  ``from_fp32_source``: the weights are the ones
+        ``Model.load_state_dict`` just wrote (or wrote before this optimiser existed and nobody has touched since), so a state
+        dict loaded in fp32 (``Model._fp32_source``) seeds its parameters at full precision.  Every other rewrite (merge,
+        broadcast, restore) must NOT look at that dict: it holds the checkpoint as loaded, not the current weights."""
         model, p = self.model, g["param"]
         master = p.float()
-        src = getattr(model, "_fp32_source", None)
+        src = getattr(model, "_fp32_source", None) if from_fp32_source else None
         if src and g["name"] != "lora":
             views, base = model._views(model.arena), model.arena.storage_offset()
             for k, t in src.items():
@@ -161,6 +163,7 @@ class FusedAdamW:
         un-counts a dropped step with ``uncount_step`` once the host has seen the flag."""
         self._settle()
         self.step_count += 1
+        self.model._fp32_source = None          # the weights move on: the loaded fp32 dict no longer describes them
         if skip is not None:
             coef = self._coef[1] if self._coef is not None else torch.ones((), dtype=F32, device=skip.device)
             self._norm_coef[1] = torch.where(skip.reshape(()) != 0, torch.full_like(coef, -1.0), coef)
@@ -188,14 +191,15 @@ class FusedAdamW:
         """A step that was dropped on the device (``step(skip=...)``) does not count towards the bias correction."""
         self.step_count = max(0, self.step_count - 1)
 
-    def params_rewritten(self, base: bool = True, lora: bool = True):
+    def params_rewritten(self, base: bool = True, lora: bool = True, from_fp32_source: bool = False):
         """The bf16 working weights were overwritten from outside (``Model.load_state_dict``, ``broadcast_parameters``,
         ``merge_lora_weights``): make them the master again.  With the split master the working copy IS the master's upper half,
-        so a stale ``lo`` would silently shift every weight by up to one bf16 ulp; re-seeding makes master == the new weights
-        (at fp32 where the loaded state dict was fp32).  Moments are kept."""
+        so a stale ``lo`` would silently shift every weight by up to one bf16 ulp; re-seeding makes master == the new weights.
+        Only ``Model.load_state_dict`` passes ``from_fp32_source`` (master at fp32 where the loaded state dict was fp32); for a
+        merge / broadcast / restore the new bf16 weights themselves are the master.  Moments are kept."""
         for g in self.param_groups:
             if lora if g["name"] == "lora" else base:
-                self.set_master(g["name"], self._seed_master(g))
+                self.set_master(g["name"], self._seed_master(g, from_fp32_source))
 
     def state_dict(self):
         return {"step": self.step_count,

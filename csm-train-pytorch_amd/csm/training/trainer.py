@@ -84,8 +84,13 @@ class CSMTrainer:
                     if m.trainable["backbone" if "backbone" in n else "decoder" if "decoder" in n else
                                    "embeddings" if "embeddings" in n else "other"])
         self.logger.info(f"Training with {total:,} trainable parameters")
-        self.grad_sync = GradSync.for_model(m) if GradSync.active() else None
-        if self.grad_sync is not None:
+        self._ensure_grad_sync()
+
+    def _ensure_grad_sync(self):
+        """(Re-)attach the gradient exchange: ``train`` closes it when it returns (GradSync.close), a later ``train`` call or a
+        direct ``train_step`` after ``prepare_optimizer`` gets a fresh one."""
+        if self.grad_sync is None and GradSync.active():
+            self.grad_sync = GradSync.for_model(self.model)
             self.grad_sync.on_skip.append(lambda step: self.optimizer.uncount_step())
 
     def train_step(self, batch, accumulation_steps: int = 1, is_boundary: bool = True, max_grad_norm: float = 1.0):
@@ -136,6 +141,7 @@ class CSMTrainer:
                       if val_dataset else None)
         if self.optimizer is None:
             self.prepare_optimizer()
+        self._ensure_grad_sync()
         if resume_from:
             self.logger.info(f"Resuming from checkpoint: {resume_from}")
             meta = load_checkpoint(resume_from, self.model, self.optimizer, self.device)
@@ -187,6 +193,11 @@ class CSMTrainer:
         if self.grad_sync is not None and self.grad_sync.skipped_steps and rank0:
             self.logger.warning(f"{len(self.grad_sync.skipped_steps)} optimiser step(s) were dropped (text-row exchange over capacity): "
                                 f"{self.grad_sync.skipped_steps}")
+        if self.grad_sync is not None:
+            # detach from the engine and give the process-global GEMM schedule switch back: a later single-GPU model in this
+            # process must not inherit the data-parallel setting.  A second train() call re-creates it.
+            self.grad_sync.close()
+            self.grad_sync = None
         return self.best_loss
 
     def _validate(self, val_loader) -> float:

@@ -461,7 +461,7 @@ __device__ __forceinline__ void gemm256_body(const Gemm256Args& g, int id, const
     if constexpr (sizeof(OutT) == 2) swb = e.mode == EPI_SWIGLU_BWD;
     if (swb) {
         if constexpr (sizeof(OutT) == 2) epi_swiglu_bwd_block<8, 4>(e, em0 + wr * 128, en0 + wc * 64, lane, acc);
-        pend = full ? 64 : 0;
+        pend = full ? 32 : 0;          // the block's 32 asm stores (its 32 gate/up loads are the compiler's: not counted)
     } else {
         pend = epi_block<OutT, 8>(e, vec_ok, em0 + wr * 128, en0 + wc * 64, lane, acc);
         if (!full) pend = 0;

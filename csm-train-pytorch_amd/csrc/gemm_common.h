@@ -213,9 +213,10 @@ struct Frags {
 // fragment read - every tile waited for the previous tile's stores to be acknowledged, which is exactly what requesting the
 // next tile's operands before the stores was meant to avoid (round 3, found in the ISA).  Unknown to the compiler, the
 // stores only make its own counted waits for epilogue LOADS stricter (counts are upper bounds of what may stay in flight).
-// (`s_nop 0`: a store of more than 8 bytes needs one wait state before its data registers may be overwritten.)
+// (`s_nop 1`: on gfx950 a store of more than 8 bytes needs TWO wait states before its data registers may be overwritten -
+// llc's hazard recognizer inserts `s_nop 1` there, and cannot see a store inside inline asm.)
 __device__ __forceinline__ void store16_asm(void* p, const U4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store8_asm(void* p, const uint2& v) {
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
@@ -406,7 +407,10 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
 // the compiler cannot hoist them itself): 16 serial round trips per wave in the 256x256 kernel, whose epilogue no other
 // workgroup on the CU overlaps.
 // Returns a lower bound of the vector-memory operations every wave issues when no lane is out of range (the persistent
-// 256x256 kernel counts its waits past them); 0 = unknown.
+// 256x256 kernels count their waits past them); 0 = unknown.  Only the inline-asm STORES are counted: `asm volatile` cannot
+// be merged or dropped, whereas the loads here are the compiler's (it may fuse or elide them), and a count that is too high
+// would let an LDS read overtake its LDS-DMA.  Too low only waits longer - and the loads precede the stores
+// that depend on them, so nothing is lost.
 template <typename OutT, int NI>
 __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int nb, int lane, const f32x4 (&acc)[NI][4]) {
     bool fast = false;
@@ -479,7 +483,7 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                     if (m < e.M) store16_asm(C + (size_t)m * e.ldc + n, pack8(v));
                 }
             }
-            return 6 * NI;        // 4 NI table loads + 2 NI stores
+            return 2 * NI;        // the 2 NI asm stores (the 4 NI table loads are the compiler's: not counted)
         }
         // ---- everything else: all residual rows of the block first
         U4 rr[NI][2];
@@ -516,7 +520,7 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                 }
             }
         }
-        return 2 * NI * (1 + (e.R ? 1 : 0) + (e.mode == EPI_SWIGLU_FWD ? 1 : 0));
+        return 2 * NI * (1 + (e.mode == EPI_SWIGLU_FWD ? 1 : 0));      // asm stores only
     }
     return 0;
 }

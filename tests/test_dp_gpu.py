@@ -151,9 +151,13 @@ def _train_worker(rank, world, port, q, outdir, cap):
                    moved=[bool((snaps[i] != (snaps[i - 1] if i else snaps[0])).any()) for i in range(8)],
                    state=m.arena.float().cpu().numpy(), persistent=__import__("csm.hip", fromlist=["lib"]).lib.csm_get_gemm256_persistent())
     else:
-        tr.grad_sync.timing = True
+        gs = tr.grad_sync
+        gs.timing = True
         tr.train(ds, batch_size=2, accumulation_steps=1, epochs=1, save_every=1)
-        res["exposed"] = tr.grad_sync.exposed_comm_ms()
+        res["exposed"] = gs.exposed_comm_ms()
+        # train() closes the exchange when it returns: hook detached, process-global GEMM switch given back
+        res["closed"] = (tr.grad_sync is None and m.engine.grad_hook is None
+                         and __import__("csm.hip", fromlist=["lib"]).lib.csm_get_gemm256_persistent() == 1)
         res["state"] = m.arena.float().cpu().numpy()
     q.put((rank, res))
     dist.barrier()
@@ -181,6 +185,7 @@ def test_two_rank_train_loop_one_writer(dev, tmp_path):
     log = open(os.path.join(out, "training.log")).read()
     assert log.count("Training completed") == 1 and log.count("Epoch 1 completed") == 1, log
     assert len(res[0]["exposed"]) == 2 and all(x >= 0 for x in res[0]["exposed"])
+    assert res[0]["closed"] and res[1]["closed"], "CSMTrainer.train must close its GradSync"
 
 
 def test_text_row_exchange_overflow_drops_the_step_and_grows(dev, tmp_path):

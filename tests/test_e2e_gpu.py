@@ -922,3 +922,39 @@ def test_optimizer_follows_rewritten_weights(dev):
     m.load_state_dict(bf)
     for name, master in opt.named_master():
         assert torch.equal(master.cpu(), bf[name].float()), f"{name}: master must equal the new bf16 weights exactly"
+
+
+def test_merge_and_broadcast_do_not_revert_to_the_loaded_checkpoint(dev):
+    """a model loaded from an fp32 state dict kept that dict (``_fp32_source``) and every later
+    ``params_rewritten`` - merge_lora_weights, broadcast_parameters, save_model's restore - re-seeded the master from it,
+    i.e. reverted the weights to the checkpoint.  Only load_state_dict may seed from the fp32 dict; a step retires it."""
+    from csm.training.optim import FusedAdamW
+    from csm.training.utils import compute_loss
+    m, _, _ = tiny_model(dev)
+    fresh = {k: (v.float() * 1.01 + 1e-4) for k, v in O.init_params(TINY, seed=78).items()}         # fp32, not bf16-representable
+    m.load_state_dict(fresh)
+    opt = FusedAdamW(m, {"backbone": 1e-2, "decoder": 1e-2, "embeddings": 1e-2, "other": 1e-2})
+    for name, master in opt.named_master():
+        assert torch.equal(master.cpu(), fresh[name]), f"{name}: an optimiser built after an fp32 load starts at fp32"
+    tokens, mask, targets = O.synthetic_batch(TINY, 2, 24, seed=5)
+    t, _ = compute_loss(m, tokens, mask, targets)
+    t.backward()
+    opt.step()
+    assert m._fp32_source is None
+    trained = m.arena.clone()
+    moved = sum(int((m._views(m.arena)[k].float().cpu() != fresh[k].to(torch.bfloat16).float()).sum()) for k in fresh)
+    assert moved > 0, "the step must have moved the weights away from the checkpoint"
+    # an outside rewrite that is not a load: new bf16 weights become the master, never the old checkpoint
+    new = (trained.float() * 0.5).to(torch.bfloat16)
+    m.arena.copy_(new)
+    m.params_rewritten()
+    assert torch.equal(m.arena, new), "params_rewritten must keep the rewritten weights"
+    for g in opt.param_groups:
+        assert torch.equal(opt.master(g["name"]), new[g["offset"]:g["offset"] + g["numel"]].float())
+    # and a rewrite right after an fp32 load (before any step) must not resurrect the loaded values either
+    m.load_state_dict(fresh)
+    m.arena.copy_(new)
+    m.params_rewritten()
+    assert torch.equal(m.arena, new)
+    for g in opt.param_groups:
+        assert torch.equal(opt.master(g["name"]), new[g["offset"]:g["offset"] + g["numel"]].float())
