@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--mode", choices=["A", "B", "C"], default="C",
                     help="A: semantic CE only (reference loss); B: + decoder on all frames; C: + decoder on 1/16 of frames")
     ap.add_argument("--lora", action="store_true", help="configs[2]: LoRA r=8 q_proj/v_proj instead of full-param")
+    ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded AdamW + parameter all-gather (ZeRO-1) "
+                    "instead of the gradient all-reduce (also: CSM_DP_ZERO1=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048, help="positions of the CPU-baseline sample (SURVEY 8d protocol: B=1, S=2048)")
     ap.add_argument("--cpu-budget", type=float, default=340.0, help="seconds the CPU-baseline leg may take (bounds the sample)")
@@ -148,7 +150,7 @@ class GemmTimer:
         def adamw(master, m, v, param, grad, *args, zero_grad=False, **kw):     # HBM-bound side of the step, timed the same way
             e0, e1 = ev()
             e0.record(); r = timer.orig_adamw(master, m, v, param, grad, *args, zero_grad=zero_grad, **kw); e1.record()
-            timer.hbm.append(((28 + (2 if zero_grad else 0)) * master.numel(), e0, e1))
+            timer.hbm.append(((28 + (2 if zero_grad else 0)) * master.numel(), e0, e1, "adamw_kernel"))
             return r
 
         self.orig_two = ops.two_linear_dw
@@ -192,7 +194,7 @@ class GemmTimer:
         def adamw_split(lo, m, v, param, grad, *args, zero_grad=False, **kw):   # master as bf16 + 16-bit halves: 26 B/param
             e0, e1 = ev()
             e0.record(); r = timer.orig_adamw_split(lo, m, v, param, grad, *args, zero_grad=zero_grad, **kw); e1.record()
-            timer.hbm.append(((26 + (2 if zero_grad else 0)) * lo.numel(), e0, e1))
+            timer.hbm.append(((26 + (2 if zero_grad else 0)) * lo.numel(), e0, e1, "adamw_split_kernel"))
             return r
 
         ops.adamw_step_split = adamw_split
@@ -212,9 +214,10 @@ class GemmTimer:
         torch.cuda.synchronize()
         if not self.hbm:
             return None
-        nbytes = sum(b for b, _, _ in self.hbm)
-        sec = sum(e0.elapsed_time(e1) for _, e0, e1 in self.hbm) * 1e-3
-        return {"kernel": "adamw_kernel", "bound": "hbm", "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        nbytes = sum(r[0] for r in self.hbm)
+        sec = sum(r[1].elapsed_time(r[2]) for r in self.hbm) * 1e-3
+        names = sorted({r[3] for r in self.hbm})             # the symbol rocprofv3 shows (ops.hip)
+        return {"kernel": "+".join(names), "launches": len(self.hbm), "bound": "hbm", "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBPS, 4), "ms_per_step": round(sec * 1e3, 3),
                 "algorithmic_bytes_per_step": nbytes}
 
@@ -247,25 +250,52 @@ class GemmTimer:
                   f"{nbytes / 1e6:7.1f} MB  {kind:14s} {kernel}", file=sys.stderr)
 
 
-def pmc_traffic(kernel):
+def kernel_source_sha16():
+    """Identity of the kernels the running library was built from: sha256 over the HIP sources (the built .so is not
+    bit-reproducible across toolchain paths, the sources are what a profile must match)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "csm-train-pytorch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.inc"))
+                    + glob.glob(os.path.join(src, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, launches_per_step=None):
     """HBM-side bytes per launch of a GEMM kernel (rocprofv3 symbol) from the committed rocprofv3 PMC passes over this same
     command (profiles/run_pmc_bench_rNN.sh -> the newest profiles/rNN_bench_pmc_traffic.json); None when there is none.
-    Counters cannot be read from inside the timed process, so this is the profile's figure, not a live one."""
+    Counters cannot be read from inside the timed process, so this is the profile's figure, not a live one - and therefore
+    only accepted when the profile was taken with THESE kernels: the file records the sha of the kernel sources it ran
+    (``_meta.kernel_source_sha16``) and its per-step launch count of the symbol; a mismatch of either returns no traffic and
+    says why (a traffic regression must not hide behind a stale profile)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_traffic.json")))
     if not files:
-        return None, None
-    t = json.load(open(files[-1])).get("_kernels", {}).get(kernel)
+        return None, "no profiles/r*_bench_pmc_traffic.json"
+    rel = os.path.relpath(files[-1], ROOT)
+    doc = json.load(open(files[-1]))
+    meta = doc.get("_meta", {})
+    have = kernel_source_sha16()
+    if meta.get("kernel_source_sha16") != have:
+        return None, f"{rel} REFUSED: taken with kernel sources {meta.get('kernel_source_sha16')}, running {have} - re-run profiles/run_pmc_bench_r04.sh"
+    t = doc.get("_kernels", {}).get(kernel)
     if not t:
-        return None, None
-    return t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        return None, f"{rel} REFUSED: no entry for the running dominant kernel {kernel}"
+    if launches_per_step and t.get("launches_per_step") and t["launches_per_step"] != launches_per_step:
+        return None, f"{rel} REFUSED: {kernel} ran {t['launches_per_step']} times per step in the profile, {launches_per_step} now"
+    return t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"], rel
 
 
-def attention_flops(args_model, B, S, n_dec_frames):
-    """Algorithmic attention FLOPs of one train step (causal half; forward + 2.5x backward)."""
+def attention_flops(args_model, B, S, n_dec_frames, factor=3.0):
+    """Attention FLOPs of one train step on the causal half.  ``factor`` 3.0 = SURVEY 8d's ALGORITHMIC count (forward + a
+    backward of twice the forward: 4 d (S/2) L per position, x3); 3.5 = what the kernels EXECUTE (the backward recomputes S
+    in both of its passes)."""
     bb, dc = args_model.bb, args_model.dc
     one = lambda c, b, s: 4.0 * b * c.num_heads * (s * s / 2.0) * c.head_dim * c.num_layers   # noqa: E731
-    return 3.5 * (one(bb, B, S) + (one(dc, n_dec_frames, args_model.args.audio_num_codebooks) if n_dec_frames else 0.0))
+    return factor * (one(bb, B, S) + (one(dc, n_dec_frames, args_model.args.audio_num_codebooks) if n_dec_frames else 0.0))
 
 
 def cpu_baseline(model, cfg_fn, seq, seed, sw, aw, budget_s):
@@ -427,6 +457,7 @@ def main():
         tr = CSMTrainer("", tempfile.mkdtemp(prefix=f"csm_bench_rank{rank}_"), device=f"cuda:{local}")   # trainer wants an output dir
         tr.logger.setLevel(30)
         tr.model = model
+        tr.zero1 = True if a.zero1 else None         # None: the CSM_DP_ZERO1 switch decides (data parallel only)
         if lora:
             apply_lora_to_model(model, r=8, alpha=16.0, target_modules=["q_proj", "v_proj"])
             if GradSync.active():
@@ -477,7 +508,7 @@ def main():
                     per_step=per_step, nb=nb)
 
     def step_flops(model, res):
-        """GEMM FLOPs of the instrumented step + algorithmic attention FLOPs (causal half, 3.5x forward for fwd+bwd)."""
+        """GEMM FLOPs of the instrumented step + algorithmic attention FLOPs (causal half, SURVEY 8d: 3x forward for fwd+bwd)."""
         kinds = res["gt"].summary() if res["gt"] is not None else {}
         n_dec = 0
         if model.acoustic_mode != "off":
@@ -525,7 +556,8 @@ def main():
         dom = max(kernels.items(), key=lambda kv: kv[1]["time_ms"]) if kernels else (None, None)
         roof = None
         if dom[0] is not None:
-            traffic, traffic_src = pmc_traffic(dom[0]) if (a.batch, a.seq, a.mode, a.lora, a.tiny) == (4, 2048, "C", False, False) else (None, None)
+            traffic, traffic_src = (pmc_traffic(dom[0], dom[1]["launches"]) if (a.batch, a.seq, a.mode, a.lora, a.tiny) == (4, 2048, "C", False, False)
+                                    else (None, "not the headline configuration"))
             roof = {"bound": "mfma", "kernel": dom[0], "kinds": dom[1]["split"], "achieved": round(dom[1]["tflops"], 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom[1]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
@@ -548,9 +580,12 @@ def main():
                        + (f"; weak scaling keeps {a.batch} sequences/GPU at every N - BASELINE config 4's 8/GPU is in extra.dp_config4_b8" if world > 1 else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq, "parallelism": f"dp{world}"},
             "codebook_tokens_per_s": round(world * cb_tokens / (dt / a.steps), 1),   # secondary: 32 per audio frame + 1 per text token
-            # GEMM FLOP + algorithmic attention FLOP (causal half, backward = 2.5x forward) of one step / step time / dense peak
+            # GEMM FLOP + ALGORITHMIC attention FLOP (causal half, fwd + bwd = 3x forward) of one step / step time / dense
+            # peak; `_executed` counts attention at the 3.5x the kernels run (S recomputed in both backward passes)
             "mfma_utilisation_step": round((gemm_flop + att_flop) / (dt / a.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if kinds else None,
-            "step_flop": {"gemm": gemm_flop, "attention": att_flop},
+            "mfma_utilisation_step_executed": round((gemm_flop + att_flop * 3.5 / 3.0) / (dt / a.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if kinds else None,
+            "step_flop": {"gemm": gemm_flop, "attention_algorithmic": att_flop, "attention_executed": att_flop * 3.5 / 3.0},
+            "kernel_source_sha16": kernel_source_sha16(),
             "hbm_kernel": gt.adamw_summary() if gt is not None else None,
             "loss": float(loss), "step_ms": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90)}, "roofline": roof,
             "rccl": rccl,
@@ -558,6 +593,15 @@ def main():
         if exposed is not None:
             out["exposed_comm_ms"] = {"mean": round(sum(exposed) / len(exposed), 3), "max": round(max(exposed), 3),
                                       "what": "per step: time the compute stream waits for the gradient collectives after the backward"}
+            zero = bool(getattr(tr.optimizer, "sharded", False))
+            out["dp_exchange"] = {"mode": "zero1 (reduce-scatter, AdamW on 1/N shards, parameter all-gather behind the step)" if zero
+                                  else "all-reduce (replicated AdamW)",
+                                  "optimizer_ms_per_step": out["hbm_kernel"]["ms_per_step"] if out["hbm_kernel"] else None,
+                                  "optimizer_params_this_rank": tr.optimizer.num_owned() if zero else tr.optimizer.num_trainable()}
+            if zero:
+                g = tr.grad_sync.param_gather_times_ms()[-a.steps:]
+                out["dp_exchange"]["param_all_gather_ms"] = {"mean": round(sum(g) / max(1, len(g)), 3), "what": "duration on the "
+                                                             "communication stream; it overlaps the next forward, which waits per layer bucket"}
     extra = {}
     if dp_b8 is not None:
         extra["dp_config4_b8"] = dp_b8

@@ -68,13 +68,15 @@ class _Stack:
 
     # -------------------------------------------------------------------------------------------- forward
     def forward(self, x: torch.Tensor, B: int, S: int, save: bool, pos: Optional[torch.Tensor] = None,
-                fuse_rope: bool = True) -> torch.Tensor:
+                fuse_rope: bool = True, on_layer_start=None) -> torch.Tensor:
         c, dev = self.c, x.device
         M, d = x.shape
         H, KV, hd, F = c.num_heads, c.num_kv_heads, c.head_dim, c.intermediate_dim
         table = self.m.rope_table(self.prefix)
         self.acts = []
         for i in range(c.num_layers):
+            if on_layer_start is not None:
+                on_layer_start(self.prefix, i)       # ZeRO-1: this layer's parameters have arrived (training/dp.py wait_params)
             a: Dict[str, torch.Tensor] = {}
             xn = torch.empty(M, d, dtype=BF16, device=dev)
             rstd1 = torch.empty(M, dtype=F32, device=dev)
@@ -378,6 +380,13 @@ class Engine:
         self.decoder = _Stack(model, "decoder")
         self.saved = None
         self.grad_hook = None   # called as hook(prefix, layer) when a layer's weight gradients are final (DP overlap)
+        # called as hook(prefix, layer) right before a forward first reads that bucket's parameters, hook(None, None) before
+        # anything else reads parameters (ZeRO-1: the updated shards are all-gathered behind the optimiser step, dp.py)
+        self.param_hook = None
+
+    def _need(self, group=None, layer=None):
+        if self.param_hook is not None:
+            self.param_hook(group, layer)
 
     # -------------------------------------------------------------------------------------------- loss forward
     def forward_loss(self, tokens: torch.Tensor, masks: torch.Tensor, targets: torch.Tensor, semantic_weight: float,
@@ -402,11 +411,13 @@ class Engine:
         if m.lora is not None and LORA_FUSE:
             m.lora.refresh()
         h0 = torch.empty(M, d, dtype=BF16, device=dev)
+        self._need("embeddings", -1)
         ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, V)
-        hidden = self.backbone.forward(h0, B, S, save)
+        hidden = self.backbone.forward(h0, B, S, save, on_layer_start=self.param_hook)
 
         # codebook-0 head + CE over positions [0, S-1) of every sequence (reference utils.py:96-106)
         logits = torch.empty(M, Vp, dtype=F32, device=dev)
+        self._need("other", -1)
         ops.linear_fwd(hidden, m.block("codebook0_head.padded"), logits)
         t0 = torch.full((B, S), -1, dtype=torch.int64, device=dev)
         t0[:, :S - 1] = tg[:, :S - 1, 0]
@@ -499,7 +510,7 @@ class Engine:
         ops.decoder_input_fwd(hidden, rows, codes, m.block("audio_embeddings.weight"), seq, V)
         x0 = torch.empty(N * K, dd, dtype=BF16, device=dev)
         ops.linear_fwd(seq, m.block("projection.weight"), x0)
-        xf = self.decoder.forward(x0, N, K, save)                                   # [N*K, dd]
+        xf = self.decoder.forward(x0, N, K, save, on_layer_start=self.param_hook)   # [N*K, dd]
         logits = torch.empty(K - 1, N, Vp, dtype=F32, device=dev)
         ah = m.block("audio_head.padded")                                           # [K-1, dd, Vp]
         xf2 = xf.view(N, K * dd)
@@ -632,6 +643,7 @@ class Engine:
         tk = tokens.reshape(M, K1).to(device=m.device, dtype=torch.int64).contiguous()
         mk = masks.reshape(M, K1).to(device=m.device, dtype=torch.uint8).contiguous()
         h0 = torch.empty(M, m.bb.embed_dim, dtype=BF16, device=m.device)
+        self._need()
         ops.embed_fwd(tk, mk, m.block("text_embeddings.weight"), m.block("audio_embeddings.weight"), h0, a.audio_vocab_size)
         return self.backbone.forward(h0, B, S, False).view(B, S, -1)
 
@@ -645,6 +657,7 @@ class Engine:
         ``model.use_kv_cache = False`` selects the cache-free prefix-recompute path (same arithmetic, kept as a check).
         """
         m, a = self.m, self.m.args
+        self._need()
         if not getattr(m, "use_kv_cache", True):
             return self._generate_frame_recompute(tokens, tokens_mask, input_pos, temperature, topk, noise)
         dev = m.device
@@ -677,6 +690,7 @@ class Engine:
         first frame of each; later frames go through ``generate_frame`` with ``[B, 1, K+1]`` tokens and a non-zero
         ``input_pos``, exactly as for one utterance."""
         m = self.m
+        self._need()
         st = m._decode_state = DecodeState(self, len(tokens_list))
         last_h = st.prefill_ragged(tokens_list, masks_list)
         return self._frame_tail(st, last_h, temperature, topk, noise)

@@ -336,6 +336,8 @@ class Model(nn.Module):
     # ------------------------------------------------------------------ state dict (reference keys)
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         out = destination if destination is not None else OrderedDict()
+        if self._engine is not None:
+            self._engine._need()         # (ZeRO-1: updated parameter shards may still be on their way, training/dp.py)
         for name, v in self._views(self.arena).items():
             out[prefix + name] = v if keep_vars else v.detach().clone()
         if self.lora is not None:

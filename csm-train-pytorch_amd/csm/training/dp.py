@@ -11,6 +11,14 @@ The text-embedding gradient is the exception to "all-reduce the slice": it is th
 in bf16), it is final only when the whole backward is (nothing left to hide its all-reduce behind), and a step touches a
 few hundred of its rows.  On the GPU the ranks therefore exchange (row id, gradient row) lists with an all-gather of a few
 MB and add them in rank order - every rank ends up with bit-identical gradients, as after an all-reduce.
+
+ZeRO-1 form (SURVEY 8e's alternative, ``CSM_DP_ZERO1=1`` / ``for_model(..., zero1=True)``): the same buckets, but each
+bucket slice is cut into ``world`` equal shards; the gradient exchange is a reduce-scatter (rank r receives the sum of shard
+r), every rank runs AdamW on its own shards only (``training/zero.py``: 1/world of the 26 B/param optimiser pass and of the
+optimiser state) and the updated bf16 parameters are all-gathered in place, bucket by bucket in the order the next forward
+uses them, on the communication stream - the forward waits per bucket (``Engine.param_hook``), so the gather hides behind
+it.  Same bytes on the wire as the all-reduce (which is a reduce-scatter + all-gather of gradients).  The text-embedding
+rows keep their list exchange and stay replicated, like every slice too small to cut.
 """
 import os
 from typing import Callable, Dict, List, Optional, Tuple
@@ -53,6 +61,22 @@ def init_nccl(rank: int, world: int, local: int):
         dist.init_process_group("nccl", **kw)
 
 
+class Piece:
+    """ZeRO-1: one contiguous run of the arenas as the optimiser sees it.  ``chunk > 0``: slice [off, off + n) is cut into
+    ``world`` shards of ``chunk`` elements and this rank owns [my_off, my_off + my_n); its reduced gradient arrives in ``grad``
+    (a segment of the shard buffer).  ``chunk == 0``: replicated - every rank holds the whole reduced gradient (``grad`` is the
+    arena view) and applies the same update."""
+    __slots__ = ("key", "off", "n", "chunk", "my_off", "my_n", "grad")
+
+    def __init__(self, key, off, n, chunk, my_off, my_n):
+        self.key, self.off, self.n, self.chunk, self.my_off, self.my_n = key, off, n, chunk, my_off, my_n
+        self.grad = None
+
+    @property
+    def group(self) -> str:
+        return self.key[0]
+
+
 class GradSync:
     """All-reduces slices of a flat gradient tensor as they become final.
 
@@ -62,10 +86,18 @@ class GradSync:
     """
 
     def __init__(self, flat_grad: torch.Tensor, buckets: Dict[tuple, List[Tuple[int, int]]], group=None,
-                 extra: Optional[List[torch.Tensor]] = None):
+                 extra: Optional[List[torch.Tensor]] = None, zero1: bool = False, flat_param: Optional[torch.Tensor] = None):
         self.flat, self.buckets, self.group = flat_grad, buckets, group
         self.extra = extra or []
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.zero1 = bool(zero1)
+        self.flat_param = flat_param                 # ZeRO-1: the parameter arena the updated shards are gathered into
+        self.pieces: List["Piece"] = []              # ZeRO-1: what this rank's optimiser owns (plan_shards)
+        self.shard_grad: Optional[torch.Tensor] = None
+        self._param_events: Dict[tuple, object] = {} # ZeRO-1: bucket key -> event after its parameter all-gather
+        self.param_gather_ms: List[float] = []
+        self._gather_events: List[tuple] = []
         self.cuda = flat_grad.is_cuda
         # high priority: the collective's few workgroups should get CUs as soon as GEMM workgroups retire, not queue behind them
         self.comm_stream = torch.cuda.Stream(priority=-1) if self.cuda else None
@@ -87,9 +119,14 @@ class GradSync:
         return dist.is_initialized() and dist.get_world_size() > 1
 
     @classmethod
-    def for_model(cls, model, group=None) -> "GradSync":
+    def for_model(cls, model, group=None, zero1: Optional[bool] = None) -> "GradSync":
         """Buckets = one per transformer layer (in backward order they complete back to front), plus the final norms,
-        the head group and the embeddings.  Registers itself as the engine's gradient-ready hook."""
+        the head group and the embeddings.  Registers itself as the engine's gradient-ready hook.  ``zero1`` (default: the
+        ``CSM_DP_ZERO1`` switch; never with LoRA, whose gradients are 2 MB): reduce-scatter + sharded optimiser + parameter
+        all-gather instead of the all-reduce - build the optimiser with ``training.zero.ZeroAdamW(model, lrs, sync)``."""
+        if zero1 is None:
+            zero1 = os.environ.get("CSM_DP_ZERO1", "0") == "1"
+        zero1 = bool(zero1) and model.lora is None
         model.ensure_grads()
         slots = model._slots
         buckets: Dict[tuple, List[Tuple[int, int]]] = {}
@@ -120,9 +157,20 @@ class GradSync:
                           pending=[])      # (optimiser step, event, slot of ``host``) per exchange, oldest first
         merged = {k: cls._merge(v) for k, v in buckets.items()}
         extra = [model.lora.grad_arena] if model.lora is not None else []
-        gs = cls(model.grad_arena, merged, group, extra)
+        gs = cls(model.grad_arena, merged, group, extra, zero1=zero1, flat_param=model.arena)
         gs.sparse = sparse
-        if gs.world_size > 1 and model.grad_arena.is_cuda and "CSM_GEMM256_PERSISTENT" not in os.environ:
+        gs._model = model
+        if zero1:
+            gs.plan_shards()
+        gs.attach()
+        return gs
+
+    def attach(self):
+        """Hook into the model's engine (gradient-ready and, for ZeRO-1, parameter-needed callbacks) and switch the GEMM
+        schedule for shared CUs; ``close`` undoes both, a later ``attach`` re-does them (trainers call train() repeatedly)."""
+        model, gs = self._model, self
+        if gs.world_size > 1 and model.grad_arena.is_cuda and "CSM_GEMM256_PERSISTENT" not in os.environ \
+                and self._restore_persistent is None:
             # The collectives' workgroups hold a few CUs while the backward runs.  A persistent GEMM launches one workgroup per CU
             # with a fixed tile list each, so the workgroups that find their CU taken would run their whole list late; one tile
             # per workgroup lets the dispatcher pack the remaining CUs instead.  (Single-GPU runs keep the persistent form.)
@@ -134,8 +182,8 @@ class GradSync:
                 "data parallel: 256x256 GEMM switched from persistent workgroups to one tile per workgroup while gradient "
                 "collectives share the CUs (CSM_GEMM256_PERSISTENT pins it; GradSync.close() restores the previous setting)")
         model.engine.grad_hook = gs.on_ready
-        gs._model = model
-        return gs
+        if self.zero1:
+            model.engine.param_hook = gs.wait_params
 
     def close(self):
         """End of data-parallel training in this process: detach from the engine, look at every outstanding overflow flag and
@@ -144,6 +192,10 @@ class GradSync:
         m = getattr(self, "_model", None)
         if m is not None and getattr(m.engine, "grad_hook", None) == self.on_ready:
             m.engine.grad_hook = None
+        if self.zero1:
+            self.wait_params(None, None)
+            if m is not None and getattr(m.engine, "param_hook", None) == self.wait_params:
+                m.engine.param_hook = None
         if self._restore_persistent is not None:
             from ..hip import lib
             lib.csm_set_gemm256_persistent(self._restore_persistent)
@@ -278,7 +330,119 @@ class GradSync:
             n = part.shape[0]
             dist.all_gather([out[r * n:(r + 1) * n] for r in range(self.world_size)], part, group=self.group)
 
+    # ------------------------------------------------------------------ ZeRO-1: shard plan, reduce-scatter, parameter gather
+    def plan_shards(self):
+        """Cut every bucket slice into ``world`` equal shards of a multiple of 8 elements (the AdamW kernels' vector width);
+        what does not divide (a tail of < 8 * world elements) and the text-embedding table (row-list exchange) stay
+        replicated: every rank updates them identically.  ``pieces`` is the optimiser's work list, in arena order."""
+        world, rank = self.world_size, self.rank
+        pieces: List[Piece] = []
+        for key, slices in self.buckets.items():
+            for off, n in slices:
+                if n % 8:
+                    raise ValueError(f"ZeRO-1: bucket slice {key} [{off}, +{n}) is not a multiple of 8 elements")
+                chunk = (n // (world * 8)) * 8
+                if chunk:
+                    pieces.append(Piece(key, off, world * chunk, chunk, off + rank * chunk, chunk))
+                if n - world * chunk:
+                    pieces.append(Piece(key, off + world * chunk, n - world * chunk, 0, off + world * chunk, n - world * chunk))
+        if self.sparse is not None:
+            o, n = self.sparse["slice"]
+            pieces.append(Piece(("embeddings", "text-rows"), o, n, 0, o, n))
+        pieces.sort(key=lambda p: p.off)
+        total = sum(p.chunk for p in pieces)
+        self.shard_grad = torch.zeros(max(total, 8), dtype=self.flat.dtype, device=self.flat.device)
+        at = 0
+        for p in pieces:
+            if p.chunk:
+                p.grad = self.shard_grad[at:at + p.chunk]
+                at += p.chunk
+            else:
+                p.grad = self.flat[p.off:p.off + p.n]
+        self.pieces = pieces
+
+    def _launch_zero(self, key):
+        """One bucket's gradients: reduce-scatter of every cut slice (rank r receives the sum of shard r into its shard
+        buffer), all-reduce of the replicated tails."""
+        self.launch_log.append(key)
+        mine = [p for p in self.pieces if p.key == key]
+        if not mine:
+            return
+
+        def run():
+            for p in mine:
+                src = self.flat[p.off:p.off + p.n]
+                if not p.chunk:
+                    dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.group)
+                elif dist.get_backend(self.group) == "nccl":
+                    dist.reduce_scatter_tensor(p.grad, src, op=dist.ReduceOp.SUM, group=self.group)
+                else:       # gloo (CPU tests, the one-GPU rehearsal): no reduce-scatter; same result from an all-reduce
+                    dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.group)
+                    p.grad.copy_(src[self.rank * p.chunk:(self.rank + 1) * p.chunk])
+        if self.cuda:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                run()
+        else:
+            run()
+
+    FORWARD_ORDER = ("embeddings", "backbone", "other", "decoder")     # the order a forward first touches the groups
+
+    def gather_params(self):
+        """After the sharded optimiser step: all-gather every cut slice of the PARAMETER arena in place (each rank's shard is
+        where it updated it), on the communication stream, bucket by bucket in the order the next forward needs them; an event
+        per bucket lets the forward wait for exactly the layer it is about to run (``wait_params``)."""
+        keys = sorted({p.key for p in self.pieces if p.chunk},
+                      key=lambda k: (self.FORWARD_ORDER.index(k[0]) if k[0] in self.FORWARD_ORDER else 9, k[1] if isinstance(k[1], int) else 0))
+        nccl = dist.get_backend(self.group) == "nccl"
+
+        def run(key):
+            for p in self.pieces:
+                if p.key != key or not p.chunk:
+                    continue
+                full = self.flat_param[p.off:p.off + p.n]
+                part = full[self.rank * p.chunk:(self.rank + 1) * p.chunk]
+                if nccl:
+                    dist.all_gather_into_tensor(full, part, group=self.group)       # in place: part IS full's shard `rank`
+                else:
+                    dist.all_gather([full[r * p.chunk:(r + 1) * p.chunk] for r in range(self.world_size)], part.clone(), group=self.group)
+        if self.cuda:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                for key in keys:
+                    run(key)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._param_events[key] = ev
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._gather_events.append((e0, e1))
+        else:
+            for key in keys:
+                run(key)
+
+    def wait_params(self, group: Optional[str], layer: Optional[int]):
+        """``Engine.param_hook``: the compute stream waits for the parameter all-gather of bucket (group, layer); with
+        ``group=None`` for all of them (anything that is not the layer-by-layer forward: generation, state_dict, close)."""
+        if not self._param_events:
+            return
+        if group is None:
+            keys = list(self._param_events)
+        else:
+            keys = [(group, layer)] if (group, layer) in self._param_events else []
+        cur = torch.cuda.current_stream() if self.cuda else None
+        for k in keys:
+            ev = self._param_events.pop(k)
+            if cur is not None:
+                cur.wait_event(ev)
+
     def _launch(self, tensors: List[torch.Tensor], key):
+        if self.zero1 and key[0] != "extra":
+            return self._launch_zero(key)
         self.launch_log.append(key)
         if not tensors:
             return
@@ -328,6 +492,15 @@ class GradSync:
                 h.wait()
         self.armed = False
         self.opt_step += 1
+
+    def param_gather_times_ms(self) -> List[float]:
+        """ZeRO-1, ``timing`` on: duration of each step's parameter all-gather on the communication stream (it overlaps the
+        next forward; what the forward actually waited is part of the step time, not separable here).  Synchronises."""
+        if self._gather_events:
+            torch.cuda.synchronize()
+            self.param_gather_ms += [a.elapsed_time(b) for a, b in self._gather_events]
+            self._gather_events = []
+        return self.param_gather_ms
 
     def exposed_comm_ms(self) -> List[float]:
         """Per optimiser step: how long the compute stream sat waiting for the communication stream at the end of the

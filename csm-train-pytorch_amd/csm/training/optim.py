@@ -36,7 +36,44 @@ def join_master(param: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
     return (((hi - (l >> 15)) << 16) | l).view(torch.float32)
 
 
+def seed_master(model, offset: int, numel: int, param: torch.Tensor, from_fp32_source: bool = False) -> torch.Tensor:
+    """fp32 master of the arena range [offset, offset + numel) from the current bf16 working weights ``param``.
+    ``from_fp32_source``: the weights are the ones ``Model.load_state_dict`` just wrote (or wrote before this optimiser
+    existed and nobody has touched since), so a state dict loaded in fp32 (``Model._fp32_source``) seeds its parameters at full
+    precision.  Every other rewrite (merge, broadcast, restore) must NOT look at that dict: it holds the checkpoint as loaded,
+    not the current weights.  (A tensor that only partly lies inside the range - a ZeRO-1 shard boundary - contributes the
+    part that does.)"""
+    master = param.float()
+    src = getattr(model, "_fp32_source", None) if from_fp32_source else None
+    if src:
+        views, base = model._views(model.arena), model.arena.storage_offset()
+        for k, t in src.items():
+            v = views.get(k)
+            if v is None:
+                continue
+            so = v.storage_offset() - base
+            end = _span_end(v, so)
+            if so >= offset and end <= offset + numel:
+                torch.as_strided(master, v.size(), v.stride(), so - offset).copy_(t.to(master.device))
+            elif so < offset + numel and end > offset:
+                # straddles the range (a sharded optimiser's piece): through a scratch image of the tensor's whole span
+                # (the image starts from what ``master`` already holds: interleaved views - w1 / w3 rows of w13 - share a span)
+                a_, b_ = max(so, offset), min(end, offset + numel)
+                scratch = torch.zeros(end - so, dtype=master.dtype, device=master.device)
+                scratch[a_ - so:b_ - so] = master[a_ - offset:b_ - offset]
+                torch.as_strided(scratch, v.size(), v.stride(), 0).copy_(t.to(master.device))
+                master[a_ - offset:b_ - offset] = scratch[a_ - so:b_ - so]
+    return master
+
+
+def _span_end(v: torch.Tensor, so: int) -> int:
+    """One past the last arena element a (possibly strided) view touches."""
+    return so + sum((sz - 1) * st for sz, st in zip(v.size(), v.stride())) + 1
+
+
 class FusedAdamW:
+    sharded = False
+
     def __init__(self, model, group_lrs: Dict[str, float], weight_decay: float = 0.01, betas=(0.9, 0.999),
                  eps: float = 1e-8, lora_lr: Optional[float] = None, lora_weight_decay: float = 0.0):
         self.model = model
@@ -73,23 +110,7 @@ class FusedAdamW:
         model._optimizers.append(weakref.ref(self))
 
     def _seed_master(self, g, from_fp32_source: bool = False) -> torch.Tensor:
-        """fp32 master of a group from the current bf16 working weights.  ``from_fp32_source``: the weights are the ones
-        ``Model.load_state_dict`` just wrote (or wrote before this optimiser existed and nobody has touched since), so a state
-        dict loaded in fp32 (``Model._fp32_source``) seeds its parameters at full precision.  Every other rewrite (merge,
-        broadcast, restore) must NOT look at that dict: it holds the checkpoint as loaded, not the current weights."""
-        model, p = self.model, g["param"]
-        master = p.float()
-        src = getattr(model, "_fp32_source", None) if from_fp32_source else None
-        if src and g["name"] != "lora":
-            views, base = model._views(model.arena), model.arena.storage_offset()
-            for k, t in src.items():
-                v = views.get(k)
-                if v is None:
-                    continue
-                so = v.storage_offset() - base
-                if g["offset"] <= so < g["offset"] + g["numel"]:
-                    torch.as_strided(master, v.size(), v.stride(), so - g["offset"]).copy_(t.to(master.device))
-        return master
+        return seed_master(self.model, g["offset"], g["numel"], g["param"], from_fp32_source and g["name"] != "lora")
 
     def named_master(self):
         """(reference parameter name, fp32 master view) for every trainable base parameter."""

@@ -50,6 +50,7 @@ class CSMTrainer:
         self.model: Optional[Model] = None
         self.optimizer: Optional[FusedAdamW] = None
         self.grad_sync: Optional[GradSync] = None
+        self.zero1: Optional[bool] = None          # data parallel only: None = the CSM_DP_ZERO1 switch, True / False pins it
         self._load_model()
         self.epoch = 0
         self.global_step = 0
@@ -79,7 +80,15 @@ class CSMTrainer:
             # replicas start from rank 0's parameters (do not rely on equal seeds / files), BEFORE the optimiser takes its
             # fp32 master copy of them
             GradSync.broadcast_parameters(m)
-        self.optimizer = FusedAdamW(m, lrs, weight_decay=self.weight_decay)
+        if GradSync.active() and (self.zero1 if self.zero1 is not None else os.environ.get("CSM_DP_ZERO1", "0") == "1"):
+            # ZeRO-1 (training/dp.py, training/zero.py): reduce-scatter -> AdamW on this rank's shards -> parameter all-gather
+            from .zero import ZeroAdamW
+            self.grad_sync = GradSync.for_model(m, zero1=True)
+            self.grad_sync.on_skip.append(lambda step: self.optimizer.uncount_step())
+            self.optimizer = ZeroAdamW(m, lrs, self.grad_sync, weight_decay=self.weight_decay)
+            self.logger.info(f"ZeRO-1: this rank updates {self.optimizer.num_owned():,} of {self.optimizer.num_trainable():,} parameters")
+        else:
+            self.optimizer = FusedAdamW(m, lrs, weight_decay=self.weight_decay)
         total = sum(p.numel() for n, p in m.named_parameters()
                     if m.trainable["backbone" if "backbone" in n else "decoder" if "decoder" in n else
                                    "embeddings" if "embeddings" in n else "other"])
@@ -90,7 +99,11 @@ class CSMTrainer:
         """(Re-)attach the gradient exchange: ``train`` closes it when it returns (GradSync.close), a later ``train`` call or a
         direct ``train_step`` after ``prepare_optimizer`` gets a fresh one."""
         if self.grad_sync is None and GradSync.active():
-            self.grad_sync = GradSync.for_model(self.model)
+            if getattr(self.optimizer, "sharded", False):
+                self.grad_sync = self.optimizer.sync          # the shard plan lives in it: re-attach, never re-plan
+                self.grad_sync.attach()
+                return
+            self.grad_sync = GradSync.for_model(self.model, zero1=False)
             self.grad_sync.on_skip.append(lambda step: self.optimizer.uncount_step())
 
     def train_step(self, batch, accumulation_steps: int = 1, is_boundary: bool = True, max_grad_norm: float = 1.0):
@@ -154,8 +167,11 @@ class CSMTrainer:
             # replicas are bit-identical: one writer (rank 0), the others wait so that nobody races ahead into a resume
             if self.grad_sync is not None:
                 self.grad_sync.check_overflow(block=True)    # every dropped step is known (and un-counted) before state is written
+            # (a sharded optimiser's state_dict is a collective: every rank calls it, rank 0 receives the tensors)
+            opt_sd = self.optimizer.state_dict() if getattr(self.optimizer, "sharded", False) else None
             if rank0:
-                save_checkpoint(self.model, self.optimizer, epoch_, self.global_step, loss_, str(self.output_dir), name)
+                save_checkpoint(self.model, self.optimizer, epoch_, self.global_step, loss_, str(self.output_dir), name,
+                                optimizer_state=opt_sd)
             if GradSync.active():
                 torch.distributed.barrier()
 

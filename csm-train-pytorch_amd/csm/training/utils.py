@@ -67,12 +67,15 @@ def compute_loss(model, input_tokens: torch.Tensor, input_masks: torch.Tensor, t
     return total, losses
 
 
-def save_checkpoint(model, optimizer, epoch: int, global_step: int, loss: float, save_dir: str, name: str = "checkpoint") -> str:
-    """Reference utils.py:526-574: one ``.pt`` dict written as ``{name}_epoch{e}_step{s}.pt`` and ``{name}_latest.pt``."""
+def save_checkpoint(model, optimizer, epoch: int, global_step: int, loss: float, save_dir: str, name: str = "checkpoint",
+                    optimizer_state=None) -> str:
+    """Reference utils.py:526-574: one ``.pt`` dict written as ``{name}_epoch{e}_step{s}.pt`` and ``{name}_latest.pt``.
+    ``optimizer_state``: an already gathered optimiser state dict (a sharded optimiser's ``state_dict`` is a collective the
+    caller runs on every rank; only the writing rank comes here)."""
     os.makedirs(save_dir, exist_ok=True)
     ckpt = {
         "model": {k: v.cpu() for k, v in model.state_dict().items()},
-        "optimizer": optimizer.state_dict() if optimizer is not None else None,
+        "optimizer": optimizer_state if optimizer_state is not None else (optimizer.state_dict() if optimizer is not None else None),
         "epoch": epoch,
         "global_step": global_step,
         "loss": float(loss),

@@ -199,6 +199,77 @@ def test_gradsync_two_ranks_gloo():
     assert all(ok for _, ok, _ in res), res
 
 
+def _zero1_worker(rank, world, port, q):
+    """ZeRO-1 exchange of training/dp.py on CPU tensors over gloo: reduce-scatter into the shard buffer, a stand-in
+    element-wise optimiser on this rank's pieces only, in-place parameter all-gather - must leave every rank with exactly the
+    parameters the all-reduce + full update leaves (the update is element-wise, the reduced gradients are the same)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))
+    from csm.training.dp import GradSync
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000 + 24                                     # slices that do not divide by 8 * world: replicated tails appear
+    buckets = {("backbone", 1): [(0, 296)], ("backbone", 0): [(296, 312)], ("other", -1): [(608, 200)], ("embeddings", -1): [(808, 216)]}
+    g0 = torch.Generator().manual_seed(5)
+    param0 = torch.randn(n, generator=g0)
+
+    def grads(step, r):
+        return torch.randn(n, generator=torch.Generator().manual_seed(100 * step + r))
+
+    def update(p, g):                                 # any element-wise rule will do
+        p.sub_(0.1 * g + 0.01 * p)
+
+    # reference: all-reduce, every rank updates everything
+    ref = param0.clone()
+    flat = torch.zeros(n)
+    gs = GradSync(flat, buckets)
+    for step in range(3):
+        flat.copy_(grads(step, rank))
+        gs.arm(True)
+        gs.on_ready("backbone", 1)
+        gs.finish()
+        update(ref, flat)
+    # ZeRO-1
+    par = param0.clone()
+    flat2 = torch.zeros(n)
+    gz = GradSync(flat2, buckets, zero1=True, flat_param=par)
+    gz.plan_shards()
+    owned = sum(p.my_n for p in gz.pieces)
+    sharded = sum(p.chunk for p in gz.pieces)
+    for step in range(3):
+        flat2.copy_(grads(step, rank))
+        gz.arm(True)
+        gz.on_ready("backbone", 1)
+        gz.finish()
+        for p in gz.pieces:
+            update(par[p.my_off:p.my_off + p.my_n], p.grad)
+        gz.gather_params()
+        gz.wait_params(None, None)
+    cover = torch.zeros(n, dtype=torch.int32)
+    for p in gz.pieces:
+        cover[p.off:p.off + p.n] += 1
+    q.put((rank, dict(equal=bool(torch.equal(par, ref)), cover_ok=bool((cover == 1).all()), owned=owned, sharded=sharded,
+                      tails=sum(p.n for p in gz.pieces if not p.chunk), log=gz.launch_log[:4])))
+    dist.destroy_process_group()
+
+
+def test_zero1_exchange_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_zero1_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for r in (0, 1):
+        assert res[r]["equal"], "ZeRO-1 (reduce-scatter, sharded update, all-gather) must equal all-reduce + full update"
+        assert res[r]["cover_ok"], "the pieces must tile the bucket slices exactly once"
+        assert res[r]["tails"] > 0 and res[r]["sharded"] > 0
+        assert res[r]["owned"] == res[r]["sharded"] + res[r]["tails"] and 2 * res[r]["sharded"] + res[r]["tails"] == 1024
+        assert res[r]["log"] == [("backbone", 1), ("backbone", 0), ("other", -1), ("embeddings", -1)]
+
+
 def _dp_helpers_worker(rank, world, port, q, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.join(ROOT, "csm-train-pytorch_amd"))

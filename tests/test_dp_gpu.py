@@ -214,6 +214,112 @@ def test_text_row_exchange_overflow_drops_the_step_and_grows(dev, tmp_path):
     assert a["persistent"] == 1, "GradSync.close() gives the process-global GEMM schedule switch back"
 
 
+def _zero_worker(rank, world, port, q, zero1, max_norm, outdir):
+    """Two optimiser steps (accumulation window 2) under DP(2), all-reduce or ZeRO-1, then a checkpoint through the trainer's
+    own save path; returns parameters and the optimiser state as rank 0 wrote it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    for p in (ROOT, os.path.join(ROOT, "csm-train-pytorch_amd")):
+        sys.path.insert(0, p)
+    from oracle import csm_oracle as O
+    from csm.models.model import Model, ModelArgs
+    from csm.training.trainer import CSMTrainer
+    from csm.training.utils import save_checkpoint
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = O.tiny_cfg()
+    m = Model(ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", cfg.text_vocab, cfg.audio_vocab, cfg.n_codebooks), device="cuda:0", seed=3 + rank)
+    # an fp32 checkpoint, loaded before the optimiser exists: masters must start at fp32 in both modes (also across shard cuts)
+    m.load_state_dict({k: v.float() * 1.003 + 1e-5 for k, v in O.init_params(cfg, seed=21).items()})
+    m.acoustic_mode = "all"
+    tr = CSMTrainer("", outdir, device="cuda:0")
+    tr.logger.setLevel(40)
+    tr.model = m
+    tr.zero1 = zero1
+    tr.prepare_optimizer()
+    assert getattr(tr.optimizer, "sharded", False) == zero1 and tr.grad_sync.zero1 == zero1
+    for step in range(2):
+        for micro in range(2):
+            tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=100 + 10 * step + 2 * micro + rank)
+            tr.train_step({"input_tokens": tokens, "input_masks": mask, "target_audio_tokens": targets}, 2, micro == 1, max_norm)
+    # what a later forward sees (goes through the per-bucket parameter waits)
+    tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=999)
+    with torch.no_grad():
+        from csm.training.utils import compute_loss
+        probe, _ = compute_loss(m, tokens, mask, targets)
+    opt_sd = tr.optimizer.state_dict()               # collective when sharded
+    torch.cuda.synchronize()
+    res = dict(state=m.arena.float().cpu().numpy(), probe=float(probe), owned=tr.optimizer.num_owned() if zero1 else None,
+               trainable=tr.optimizer.num_trainable(), log=list(tr.grad_sync.launch_log)[:6])
+    if rank == 0:
+        res["opt"] = {g: {k: v.numpy() for k, v in st.items()} for g, st in opt_sd["state"].items()}
+        res["opt_step"] = opt_sd["step"]
+        path = save_checkpoint(m, tr.optimizer, 1, 2, 0.0, outdir, "zero", optimizer_state=opt_sd if zero1 else None)
+        res["ckpt"] = path
+    dist.barrier()
+    # resume: a fresh trainer in the same mode loads the checkpoint rank 0 wrote and lands on the same state
+    m2 = Model(ModelArgs("llama-tiny-backbone", "llama-tiny-decoder", cfg.text_vocab, cfg.audio_vocab, cfg.n_codebooks), device="cuda:0", seed=77)
+    tr2 = CSMTrainer("", outdir + "_b", device="cuda:0")
+    tr2.logger.setLevel(40)
+    tr2.model = m2
+    tr2.zero1 = zero1
+    tr2.prepare_optimizer()
+    from csm.training.utils import load_checkpoint
+    import glob
+    load_checkpoint(sorted(glob.glob(os.path.join(outdir, "zero_epoch1_step2.pt")))[0], m2, tr2.optimizer)
+    sd2 = tr2.optimizer.state_dict()
+    torch.cuda.synchronize()
+    res["resumed_params_equal"] = bool(torch.equal(m2.arena, m.arena))
+    if rank == 0:
+        res["resumed_opt_equal"] = all(torch.equal(sd2["state"][g][k], opt_sd["state"][g][k]) for g in opt_sd["state"] for k in ("master", "m", "v"))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_zero(tmp_path, zero1, max_norm, tag):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32100 + os.getpid() % 1000 + (7 if zero1 else 0) + (3 if max_norm else 0)
+    procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q, zero1, max_norm, str(tmp_path / tag))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=400) for _ in procs)
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def test_zero1_matches_allreduce_dp_bit_for_bit(dev, tmp_path):
+    """SURVEY 8e's ZeRO-1 option (reduce-scatter -> AdamW on this rank's shards -> parameter all-gather) against the all-reduce
+    path, two ranks on the one GPU (gloo carries the tensors).  The update is the same element-wise kernel on the same reduced
+    gradients, so WITHOUT clipping parameters, fp32 masters and both moments must be bit-identical between the two modes -
+    and the replicas bit-identical to each other; with clipping the norm is summed in a different order (shards + one scalar
+    all-reduce), so the result may differ by rounding of one coefficient.  The checkpoint format is the same and resumes."""
+    ar = _run_zero(tmp_path, False, 0.0, "ar")
+    z = _run_zero(tmp_path, True, 0.0, "z")
+    assert (z[0]["state"] == z[1]["state"]).all(), "ZeRO-1 replicas diverged"
+    assert z[0]["probe"] == z[1]["probe"]
+    assert (z[0]["state"] == ar[0]["state"]).all(), "ZeRO-1 parameters differ from the all-reduce path's"
+    assert z[0]["probe"] == ar[0]["probe"], "a forward after the step must see the gathered parameters"
+    assert z[0]["opt_step"] == ar[0]["opt_step"] == 2
+    for g in ar[0]["opt"]:
+        for k in ("master", "m", "v"):
+            assert (z[0]["opt"][g][k] == ar[0]["opt"][g][k]).all(), f"optimiser state {g}.{k} differs between the modes"
+    # each rank owns about half of the trained parameters (+ the replicated text-embedding table and tails)
+    assert z[0]["owned"] < z[0]["trainable"] and z[1]["owned"] < z[1]["trainable"]
+    assert z[0]["owned"] + z[1]["owned"] >= z[0]["trainable"]
+    assert z[0]["resumed_params_equal"] and z[1]["resumed_params_equal"] and z[0]["resumed_opt_equal"]
+    assert ar[0]["resumed_params_equal"] and ar[0]["resumed_opt_equal"]
+    # with global-norm clipping: same to within the rounding of the coefficient
+    arc = _run_zero(tmp_path, False, 1.0, "arc")
+    zc = _run_zero(tmp_path, True, 1.0, "zc")
+    assert (zc[0]["state"] == zc[1]["state"]).all(), "ZeRO-1 replicas diverged (clipped)"
+    import numpy as np
+    d = np.abs(zc[0]["state"] - arc[0]["state"])
+    assert d.max() <= 2e-3 * np.abs(arc[0]["state"]).max() + 4.2e-3 and (d > 1e-3).mean() < 0.02, d.max()
+    assert (np.abs(arc[0]["state"] - ar[0]["state"]) > 0).any(), "the clip must have been active in this test"
+
+
 def _rccl_worker(port, q):
     """World size 1 over the REAL RCCL backend: no traffic leaves the GPU, but every RCCL-only code path of training/dp.py
     executes on hardware - init_nccl with the high-priority stream option, all_gather_into_tensor in the text-row exchange,
@@ -261,9 +367,30 @@ def _rccl_worker(port, q):
             l1, _ = tr1.train_step(b, 1, True, 1.0)
             assert float(l0) == float(l1), (step, float(l0), float(l1))
         gs.close()
+        # ZeRO-1 over the real RCCL group: reduce_scatter_tensor / in-place all_gather_into_tensor with one rank are identities
+        m2, tr2 = build(3)
+        tr2.zero1 = True
+        tr2.prepare_optimizer()
+        gz = tr2.grad_sync
+        assert gz.zero1 and tr2.optimizer.sharded and tr2.optimizer.num_owned() == tr2.optimizer.num_trainable()
+        gz.world_size = 1
+        real_arm2 = gz.arm
+        gz.arm = lambda enabled=True: (real_arm2(enabled), setattr(gz, "armed", bool(enabled)))
+        m3, tr3 = build(3)
+        dp.GradSync.active = real_active
+        tr3.prepare_optimizer()
+        dp.GradSync.active = staticmethod(lambda: True)
+        for step in range(3):
+            tokens, mask, targets = O.synthetic_batch(cfg, 2, 24, seed=300 + step)
+            b = {"input_tokens": tokens, "input_masks": mask, "target_audio_tokens": targets}
+            l2, _ = tr2.train_step(b, 1, True, 1.0)
+            l3, _ = tr3.train_step(b, 1, True, 1.0)
+            assert float(l2) == float(l3), ("zero1", step, float(l2), float(l3))
+        gz.close()
         torch.cuda.synchronize()
         q.put(dict(equal=bool(torch.equal(m0.arena, m1.arena)), log=list(gs.launch_log)[:12], skipped=list(gs.skipped_steps),
-                   backend=dist.get_backend(), persistent_after_close=lib.csm_get_gemm256_persistent()))
+                   backend=dist.get_backend(), persistent_after_close=lib.csm_get_gemm256_persistent(),
+                   zero_equal=bool(torch.equal(m2.arena, m3.arena)), zero_log=list(gz.launch_log)[:4]))
     finally:
         dp.GradSync.active = real_active
     dist.destroy_process_group()
@@ -283,3 +410,4 @@ def test_rccl_paths_execute_on_one_rank(dev):
     assert res["equal"], "a 1-rank RCCL DP step must be the identity on the gradients"
     assert ("embeddings", "text-rows") in res["log"] and not res["skipped"], res
     assert res["persistent_after_close"] == 1
+    assert res["zero_equal"], "1-rank ZeRO-1 over RCCL (reduce-scatter, sharded AdamW, all-gather) must equal the plain step"

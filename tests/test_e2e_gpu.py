@@ -958,3 +958,25 @@ def test_merge_and_broadcast_do_not_revert_to_the_loaded_checkpoint(dev):
     assert torch.equal(m.arena, new)
     for g in opt.param_groups:
         assert torch.equal(opt.master(g["name"]), new[g["offset"]:g["offset"] + g["numel"]].float())
+
+
+def test_seed_master_on_shard_ranges_equals_full_range(dev):
+    """ZeRO-1 (training/zero.py) seeds the fp32 master of arbitrary arena ranges: a parameter that straddles a shard cut -
+    including the interleaved w1 / w3 rows of the fused w13 block - must contribute exactly the part inside the range."""
+    from csm.training.optim import seed_master
+    m, _, _ = tiny_model(dev)
+    fresh = {k: (v.float() * 1.01 + 1e-4) for k, v in O.init_params(TINY, seed=79).items()}
+    m.load_state_dict(fresh)
+    for grp in ("backbone", "decoder", "embeddings", "other"):
+        o, n = m.group_range(grp)
+        full = seed_master(m, o, n, m.arena[o:o + n], True)
+        assert not torch.equal(full, m.arena[o:o + n].float()), "the fp32 source must have been used"
+        cuts = [0, 8, 1000 // 8 * 8, n // 3 // 8 * 8, n // 2 // 8 * 8 + 8, n - 8, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b <= a:
+                continue
+            part = seed_master(m, o + a, b - a, m.arena[o + a:o + b], True)
+            assert torch.equal(part, full[a:b]), (grp, a, b)
+    # and without the source flag: the bf16 weights themselves
+    o, n = m.group_range("backbone")
+    assert torch.equal(seed_master(m, o + 8, 64, m.arena[o + 8:o + 72], False), m.arena[o + 8:o + 72].float())

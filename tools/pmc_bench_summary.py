@@ -5,9 +5,11 @@ Units / corrections per MI355X_MICROARCH.md (HBM section): both counters are in 
 128-B requests of a wide coalesced stream at 64 B, so the read side is doubled; WRITE_SIZE is exact for 16-B stores.
 Writes a table to stdout and, with a third argument, a JSON keyed by bench.py's GEMM kinds (nt_fwd_bf16, ...) that
 bench.py reads back into ``roofline.traffic``.
-Usage: python tools/pmc_bench_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+The JSON records which kernels it measured (``_meta.kernel_source_sha16`` = bench.py's hash of csrc/, and per symbol the
+launches per train step): bench.py refuses the file when either disagrees with the running library.
+Usage: python tools/pmc_bench_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json [train steps in the run]]
 """
-import collections, csv, json, re, sys
+import collections, csv, json, os, re, sys
 
 
 def load(path, counter):
@@ -45,8 +47,13 @@ if len(sys.argv) > 3:
     out = {kd: {"hbm_read_bytes_per_launch": v[0] / v[2], "hbm_write_bytes_per_launch": v[1] / v[2], "launches_profiled": v[2]}
            for kd, v in agg.items()}
     # per kernel symbol (template arguments kept, argument list dropped): what bench.py's roofline.kernel names
-    out["_kernels"] = {k: {"hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n, "launches_profiled": n}
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    out["_kernels"] = {k: {"hbm_read_bytes_per_launch": rd / n, "hbm_write_bytes_per_launch": wr / n, "launches_profiled": n,
+                           "launches_per_step": (n // steps if steps and n % steps == 0 else None)}
                        for k, (rd, wr, n) in tot.items() if k.startswith("gemm")}
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    out["_meta"] = {"kernel_source_sha16": bench.kernel_source_sha16(), "train_steps_profiled": steps}
     out["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 --warmup 1 " \
                      "--no-cpu-baseline`; FETCH_SIZE x2 (gfx950 128-B request correction), KiB -> bytes"
     json.dump(out, open(sys.argv[3], "w"), indent=1)
