@@ -52,6 +52,7 @@ _SIGS = {
     "csm_colsum_rows_bf16": ([_p, _i, _ll, _i, _p, _i, _p], _i),
     "csm_rope": ([_p, _p, _p, _ll, _i, _i, _i, _i, _i, _p], _i),
     "csm_set_attn_variant": ([_i], _i),
+    "csm_attn_last_dkv_kernel": ([], _i),
     "csm_attn_fwd": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd_rope": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),

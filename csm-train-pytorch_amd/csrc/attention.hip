@@ -593,6 +593,12 @@ static int g_attn_gen2 = 3;                          // head_dim 64: second-gene
 int csm_attn64_fwd_launch(const void* qkv, void* out, float* lse, int B, int S, int H, int KV, hipStream_t stream);
 int csm_attn64_dkv_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
                           int KV, const float* rope, hipStream_t stream);
+int csm_attn64_dkv_asm_launch(const void* qkv, const void* dout, const float* stats, void* dqkv, int B, int S, int H, int KV,
+                              const float* rope, hipStream_t stream);
+extern int g_attn64_dkv_asm_order;
+static int g_attn_last_dkv = 0;
+extern "C" int csm_attn_last_dkv_kernel(void) { return g_attn_last_dkv; }
+static int g_attn_dkv_asm = 1;                       // csm_set_attn_variant bit 10 switches the asm dK/dV kernel off (A/B)
 int csm_attn64_dq_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int S,
                          int H, int KV, const float* rope, hipStream_t stream);
 extern "C" int csm_set_attn_variant(int v) {
@@ -600,7 +606,8 @@ extern "C" int csm_set_attn_variant(int v) {
     // forward / dQ kernel (1 | 2; 0 = 1); bits 4..5 dK/dV work order (0 plain, 1 / 2 complementary pairing, 3 heaviest key blocks first);
     // bit 6 dK/dV key tile (1: 64 keys per workgroup, 0: 128); bit 7 forward / dQ work order heaviest q-blocks first.
     // bits 8..9: 0 = second-generation head_dim-64 kernels (attention64.hip; the default), 1 = first generation forward,
-    // 2 = first generation backward, 3 = both first generation (A/B reference).
+    // 2 = first generation backward, 3 = both first generation (A/B reference).  bit 10: dK/dV through attention64.hip's
+    // second-generation kernel instead of the generated-asm one of attention64_asm.hip.
     if (v == 0) v = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7);
     g_attn_gen2 = 3 & ~((v >> 8) & 3);
     g_attn_qt_fwd = (v & 3) == 2 ? 2 : 1;
@@ -608,6 +615,8 @@ extern "C" int csm_set_attn_variant(int v) {
     g_attn_dkv_map = (v >> 4) & 3;
     g_attn_dkv_kt1 = (v >> 6) & 1;
     g_attn_q_lpt = (v >> 7) & 1;
+    g_attn_dkv_asm = !((v >> 10) & 1);               // bit 10: second-generation dK/dV kernel instead of the asm one
+    g_attn64_dkv_asm_order = (v >> 11) & 1;          // bit 11: asm dK/dV kernel walks an XCD's (batch, kv head) pairs one after the other
     return 0;
 }
 
@@ -631,6 +640,7 @@ extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S
 static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
                          const float* rope, int B, int S, int H, int KV, int HD, hipStream_t stream) {
     if (int e = check_attn("csm_attn_bwd", B, S, H, KV, HD)) return e;
+    g_attn_last_dkv = 0;
     CSM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, "csm_attn_bwd: null pointer");
     const float scale = 1.f / sqrtf((float)HD);
     // dQ first: it also writes delta = rowsum(dO * O), which the dK/dV kernel reads
@@ -641,8 +651,11 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
         else if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         else launch_q<64, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
-        if (g_attn_gen2 & 2) csm_attn64_dkv_launch(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
-        else if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        if (g_attn_gen2 & 2) {
+            // third generation (attention64_asm.hip: one wave per 64 keys and query head, generated asm loop) where the shape allows
+            g_attn_last_dkv = g_attn_dkv_asm && csm_attn64_dkv_asm_launch(qkv, dout, delta_ws, dqkv, B, S, H, KV, rope, stream);
+            if (!g_attn_last_dkv) csm_attn64_dkv_launch(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
+        } else if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
     } else {
         launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);

@@ -770,6 +770,10 @@ __global__ __launch_bounds__(256, 2) void attn64_dkv_kernel(const bf16_t* __rest
                 dk0[i] += red[(i) * 64 + lane]; dk1[i] += red[(16 + i) * 64 + lane];
                 dv0[i] += red[(32 + i) * 64 + lane]; dv1[i] += red[(48 + i) * 64 + lane];
             }
+            // (the sums must be in registers BEFORE the barrier: the row staging below overwrites `red`, and hipcc may sink
+            //  these LDS reads to their first use behind it - seen in attention64_asm.hip, round 4; an empty asm pins them)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(dk0[i]), "+v"(dk1[i]), "+v"(dv0[i]), "+v"(dv1[i]));
         }
         __syncthreads();
         if (qp == 0) {

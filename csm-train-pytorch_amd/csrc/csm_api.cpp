@@ -18,7 +18,8 @@ extern "C" void csm_set_error(const char* fmt, ...) {
 extern "C" const char* csm_last_error(void) { return g_err; }
 
 // 2: csm_attn_bwd's scratch doubled (csm_attn_bwd_workspace_bytes), negative clip coefficient = skipped AdamW step
-extern "C" int csm_abi_version(void) { return 2; }
+// 3: added entry points only (csm_attn_last_dkv_kernel, ...): every ABI-2 call keeps its meaning
+extern "C" int csm_abi_version(void) { return 3; }
 extern "C" long long csm_attn_bwd_workspace_bytes(int B, int S, int H) { return 2LL * B * H * S * (long long)sizeof(float); }
 
 // 0 when a gfx950 device is visible to this process, otherwise an error code with text.

@@ -105,7 +105,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib.csm_abi_version() == 2
+    assert hip.lib.csm_abi_version() == 3
 
 
 def test_product_path_has_no_cpu_fallback():

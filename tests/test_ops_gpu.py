@@ -960,3 +960,46 @@ def test_gemm_four_wave_kernel_fused_epilogues(dev):
     for key in ("w4", "w4_one"):
         for a, b in zip(res["w8"], res[key]):
             assert torch.equal(a, b), key
+
+
+@pytest.mark.parametrize("B,S,H,KV", [(1, 64, 4, 1), (1, 128, 4, 1), (2, 192, 8, 2), (1, 512, 8, 2), (2, 320, 4, 1), (1, 2048, 8, 2)])
+def test_attention_dkv_generated_asm_kernel(dev, B, S, H, KV):
+    """attention64_asm.hip (round 4): the dK/dV pass as one wave per (64 keys, query head) with a generated, hand-allocated asm
+    loop.  Against the fp32 oracle (same tolerance as test_attention), against the second-generation kernel it replaces
+    (csm_set_attn_variant bit 10 switches it off: the two differ only in the order the four heads / two parities are summed),
+    with and without the RoPE^T epilogue, both work orders (bit 11), and bit-identical from run to run."""
+    from csm.hip import ops
+    from csm.models.model import llama3_rope_table
+    hd = 64
+    g = torch.Generator().manual_seed(7 * S + H)
+    qkv = rnd((B * S, (H + 2 * KV) * hd), g)
+    dout = rnd((B * S, H * hd), g)
+    qr = qkv.float().requires_grad_(True)
+    _attn_ref(qr, B, S, H, KV, hd).backward(dout.float())
+    gq = qr.grad
+    qd, dd = qkv.to(dev), dout.to(dev)
+    out = torch.empty(B * S, H * hd, dtype=BF, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd(qd, out, lse, B, S, H, KV, hd)
+    delta = torch.empty(2, B, H, S, dtype=torch.float32, device=dev)
+    table = llama3_rope_table(S, hd, 500000.0, 32.0).to(dev).contiguous()
+    kv = slice(H * hd, None)
+    DEFAULTS = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7)
+    res = {}
+    try:
+        for name, v in (("gen2", DEFAULTS | (1 << 10)), ("asm", 0), ("asm_pairs", DEFAULTS | (1 << 11)), ("asm_again", 0)):
+            ops.lib.csm_set_attn_variant(v)
+            for rope in (None, table):
+                dqkv = torch.full_like(qd, float("nan"))
+                ops.attn_bwd(qd, out, dd, lse, dqkv, delta, B, S, H, KV, hd, rope_table=rope)
+                res[name, rope is not None] = dqkv.clone()
+    finally:
+        ops.lib.csm_set_attn_variant(0)
+    assert ops.lib.csm_attn_last_dkv_kernel() == 1, "the asm kernel must have taken this shape"
+    close("asm dk", res["asm", False][:, H * hd:(H + KV) * hd], gq[:, H * hd:(H + KV) * hd], 2e-2)
+    close("asm dv", res["asm", False][:, (H + KV) * hd:], gq[:, (H + KV) * hd:], 2e-2)
+    for rope in (False, True):
+        assert not torch.isnan(res["asm", rope].float()).any()
+        close("asm vs second generation", res["asm", rope][:, kv], res["gen2", rope][:, kv].float(), 2e-3)
+        assert torch.equal(res["asm", rope], res["asm_again", rope]), "run-to-run bit-identical"
+        assert torch.equal(res["asm", rope], res["asm_pairs", rope]), "the work order must not change a bit"
