@@ -53,6 +53,7 @@ _SIGS = {
     "csm_rope": ([_p, _p, _p, _ll, _i, _i, _i, _i, _i, _p], _i),
     "csm_set_attn_variant": ([_i], _i),
     "csm_attn_last_dkv_kernel": ([], _i),
+    "csm_attn64_set_debug": ([_p], _i),
     "csm_attn_fwd": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd_rope": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),

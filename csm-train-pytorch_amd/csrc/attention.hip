@@ -595,9 +595,12 @@ int csm_attn64_dkv_launch(const void* qkv, const void* dout, const float* lse, c
                           int KV, const float* rope, hipStream_t stream);
 int csm_attn64_dkv_asm_launch(const void* qkv, const void* dout, const float* stats, void* dqkv, int B, int S, int H, int KV,
                               const float* rope, hipStream_t stream);
-extern int g_attn64_dkv_asm_order;
-static int g_attn_last_dkv = 0;
-extern "C" int csm_attn_last_dkv_kernel(void) { return g_attn_last_dkv; }
+extern int g_attn64_dkv_asm_order, g_attn64_dq_asm_order;
+int csm_attn64_dq_asm_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* stats, void* dqkv, int B, int S,
+                             int H, int KV, const float* rope, hipStream_t stream);
+static int g_attn_last_dkv = 0, g_attn_last_dq = 0, g_attn_dq_asm = 1;
+// bit 0: the dK/dV pass, bit 1: the dQ pass of the most recent csm_attn_bwd* call ran the generated-asm kernel
+extern "C" int csm_attn_last_dkv_kernel(void) { return g_attn_last_dkv | (g_attn_last_dq << 1); }
 static int g_attn_dkv_asm = 1;                       // csm_set_attn_variant bit 10 switches the asm dK/dV kernel off (A/B)
 int csm_attn64_dq_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int S,
                          int H, int KV, const float* rope, hipStream_t stream);
@@ -616,6 +619,8 @@ extern "C" int csm_set_attn_variant(int v) {
     g_attn_dkv_kt1 = (v >> 6) & 1;
     g_attn_q_lpt = (v >> 7) & 1;
     g_attn_dkv_asm = !((v >> 10) & 1);               // bit 10: second-generation dK/dV kernel instead of the asm one
+    g_attn_dq_asm = !((v >> 12) & 1);                // bit 12: second-generation dQ kernel instead of the asm one
+    g_attn64_dq_asm_order = (v >> 13) & 1;           // bit 13: asm dQ kernel one query block per workgroup (not persistent)
     g_attn64_dkv_asm_order = (v >> 11) & 1;          // bit 11: asm dK/dV kernel walks an XCD's (batch, kv head) pairs one after the other
     return 0;
 }
@@ -640,15 +645,17 @@ extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S
 static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
                          const float* rope, int B, int S, int H, int KV, int HD, hipStream_t stream) {
     if (int e = check_attn("csm_attn_bwd", B, S, H, KV, HD)) return e;
-    g_attn_last_dkv = 0;
+    g_attn_last_dkv = g_attn_last_dq = 0;
     CSM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, "csm_attn_bwd: null pointer");
     const float scale = 1.f / sqrtf((float)HD);
     // dQ first: it also writes delta = rowsum(dO * O), which the dK/dV kernel reads
     void* o = const_cast<void*>(out);
     float* l = const_cast<float*>(lse);
     if (HD == 64) {
-        if (g_attn_gen2 & 2) csm_attn64_dq_launch(qkv, out, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
-        else if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        if (g_attn_gen2 & 2) {
+            g_attn_last_dq = g_attn_dq_asm && csm_attn64_dq_asm_launch(qkv, out, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
+            if (!g_attn_last_dq) csm_attn64_dq_launch(qkv, out, dout, lse, delta_ws, dqkv, B, S, H, KV, rope, stream);
+        } else if (S > 64 && g_attn_qt_bwd == 2) launch_q<64, true, 2>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         else launch_q<64, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
         if (g_attn_gen2 & 2) {

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <type_traits>
 #include "attn64_dkv_loop.inc"
+#include "attn64_dq_loop.inc"
 
 namespace {
 
@@ -171,6 +172,187 @@ __global__ __launch_bounds__(256, 1) void attn64_dkv_asm_kernel(const bf16_t* __
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// dQ pass, same construction (tools/gen/gen_attn64_dq_loop.py): one wave = 64 queries (two 32-query tiles, the query on the
+// lane) of one query head, its Q^T / dO^T operands in AGPRs, walking the 32-key tiles from the diagonal down to key 0.  The four
+// waves of a workgroup are the four query heads of one GQA group on the same 64-query block: they consume the same K / V tiles,
+// so the workgroup shares ONE eight-stage ring, each wave fetching a quarter of every tile, one barrier per tile.  Also computes delta = rowsum(dO o O) and publishes -delta and
+// -lse * log2(e) for the dK/dV pass, and applies the RoPE backward in the epilogue (rope != null) - as attn64_dq_kernel does.
+constexpr int QRING = CSM_A64_DQ_STAGE * CSM_A64_DQ_NSTAGE;      // the workgroup's K / V ring: 64 KiB
+constexpr int QSTAGING = 2 * 32 * 144;                          // per wave, behind the ring: its two 32-query dQ tiles as [q][d] rows
+
+__device__ __forceinline__ float halves_sum(float x) {          // lanes l and l ^ 32 hold the same query
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+__global__ __launch_bounds__(256, 1) void attn64_dq_asm_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                               float* __restrict__ stats, bf16_t* __restrict__ dqkv, int S, int H, int KV,
+                                                               float scale, const float* __restrict__ rope, long long nstat, unsigned c2,
+                                                               int levels /* query blocks per round of the persistent schedule */,
+                                                               unsigned long long* __restrict__ dbg /* tools/probes: cycle stamps, or null */) {
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    const int nqblk = S / 64;
+    // Persistent schedule: workgroup w = (pair = w % P, level = w / P) keeps its (batch, kv head) pair - its XCD keeps that pair's
+    // K / V in L2 - and walks the query blocks nq-1-(L r + level') for r = 0, 1, ...: level' = level in even rounds, L-1-level in
+    // odd ones, so every workgroup gets the same total stream length (the per-workgroup fixed cost - dispatch, first loads,
+    // epilogue - is paid once per workgroup instead of once per block when the rounds are real loop trips).
+    const int P = gridDim.x / levels;
+    const int pair = blockIdx.x % P, level = blockIdx.x / P;
+    const int kvh = pair % KV, b = pair / KV;
+    const int ld = (H + 2 * KV) * 64, ldo = H * 64;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hq = kvh * 4 + wave;
+  for (int round = 0; round * levels < nqblk; ++round) {
+    const int jb = nqblk - 1 - (round * levels + ((round & 1) ? levels - 1 - level : level));
+    if (jb < 0) continue;                                 // (uniform over the workgroup)
+    if (round) __syncthreads();                           // the ring is free again: every wave has left the previous block's loop
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+    if (dbg) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    const int q0 = jb * 64;
+    const int ntiles = __builtin_amdgcn_readfirstlane(2 * jb + 2);             // 32-key tiles at or below the block's diagonal
+
+    const unsigned sbase = (unsigned)(uintptr_t)smem;                            // the ring is the workgroup's
+    const unsigned wbase = __builtin_amdgcn_readfirstlane(sbase + (unsigned)wave * 1024u);   // this wave writes piece `wave` of every image
+    const unsigned roff0 = sbase + r * 128 + ((h ^ swz(r)) << 4);
+    unsigned toff00;
+    {
+        const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+        const int row = 4 * (g >> 1) + q4, ch = 2 * (g & 1) + (p >> 1);
+        toff00 = sbase + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
+    }
+    unsigned dk[2], qo[2], oo[2];
+    {
+        const int row = 8 * wave + (lane >> 3);                                // rows 8 wave .. 8 wave + 7 of a tile
+        dk[0] = (unsigned)(row * ld + (((lane & 7) ^ swz(row)) << 3)) * 2u;
+        dk[1] = 0;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        qo[p] = (unsigned)((q0 + 32 * p + r) * ld + 8 * h) * 2u;           // (p = query tile)
+        oo[p] = (unsigned)((q0 + 32 * p + r) * ldo + 8 * h) * 2u;
+    }
+    const int m0v = r - 4 * h;
+    const char* Kb = reinterpret_cast<const char*>(qkv + (size_t)b * S * ld + (H + kvh) * 64);
+    const char* Vb = reinterpret_cast<const char*>(qkv + (size_t)b * S * ld + (H + KV + kvh) * 64);
+    const char* Qb = reinterpret_cast<const char*>(qkv + (size_t)b * S * ld + hq * 64);
+    const char* Ob = reinterpret_cast<const char*>(dout + (size_t)b * S * ldo + hq * 64);
+    const unsigned kstep = 32u * ld * 2u;
+
+#define CSM_A64_DQ_OPERANDS                                                                                              \
+    ::"v"(roff0), "v"(toff00), "v"(dk[0]), "v"(dk[1]), "v"(qo[0]), "v"(qo[1]), "v"(oo[0]), "v"(oo[1]), "v"(nd[0]), "v"(nd[1]),       \
+        "v"(nl[0]), "v"(nl[1]), "v"(m0v), "s"(Kb), "s"(Vb), "s"(Qb), "s"(Ob), "s"(ntiles), "s"(wbase), "s"(kstep), "s"(c2)
+    // block 1: every request the loop starts from (Q^T / dO^T operands -> AGPRs, this wave's pieces of the first tiles), no wait:
+    // the delta computation's and the RoPE table's loads below overlap them
+    float nd[2] = {0.f, 0.f}, nl[2] = {0.f, 0.f};
+    asm volatile(CSM_A64_DQ_PRO CSM_A64_DQ_OPERANDS : CSM_A64_DQ_PRO_CLOBBERS);
+    unsigned long long sta = 0, stb = 0;
+    if (dbg) sta = __builtin_readcyclecounter();
+
+    // ---- delta = rowsum(dO o O) and the exp2 addend of this lane's two queries; published for the dK/dV pass
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 32 * qt + r;
+        const bf16_t* op = out + ((size_t)b * S + q) * ldo + hq * 64 + 8 * h;
+        const bf16_t* dp = dout + ((size_t)b * S + q) * ldo + hq * 64 + 8 * h;
+        float dsum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dp + 16 * ks);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += bf2f((bf16_t)dof[j]) * bf2f((bf16_t)of[j]);
+        }
+        nd[qt] = -halves_sum(dsum);
+        nl[qt] = -lse[((size_t)b * H + hq) * S + q] * 1.4426950408889634f;
+        if (h == 0) {
+            stats[((size_t)b * H + hq) * S + q] = nd[qt];
+            stats[(size_t)nstat + ((size_t)b * H + hq) * S + q] = nl[qt];
+        }
+    }
+
+    if (dbg) stb = __builtin_readcyclecounter();
+    // RoPE table entries of this lane's two queries, requested before the loop and used after it
+    float4 rt[2][4][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            rt[qt][gq][0] = rt[qt][gq][1] = make_float4(1.f, 0.f, 1.f, 0.f);
+            if (rope) {
+                const float* tr = rope + ((size_t)(q0 + 32 * qt + r) * 32 + 4 * gq + 2 * h) * 2;
+                rt[qt][gq][0] = *reinterpret_cast<const float4*>(tr);
+                rt[qt][gq][1] = *reinterpret_cast<const float4*>(tr + 32);
+            }
+        }
+
+    // The NEXT block's Q / dO / O rows (one 128-B line per row and tensor, cold in HBM: fetched by every CU at once they cost
+    // ~12k cycles in front of the loop - the prologue burst runs at the HBM rate, ~11 B/cycle/CU): one dword per line requested
+    // now brings them into this XCD's L2 while the loop runs.  Lane = row of the next 64-query block; results unused.
+    unsigned touch[3] = {0u, 0u, 0u};
+    {
+        const int nr = round + 1;
+        const int jn = nqblk - 1 - (nr * levels + ((nr & 1) ? levels - 1 - level : level));
+        if (jn >= 0) {
+            const size_t row = (size_t)b * S + jn * 64 + lane;
+            // (inline asm: a load the compiler knows about is waited for in front of the loop block; the registers stay reserved
+            //  until the empty asm behind the loop names them)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch[0]) : "v"(qkv + row * ld + hq * 64));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch[1]) : "v"(dout + row * ldo + hq * 64));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch[2]) : "v"(out + row * ldo + hq * 64));
+        }
+    }
+    if (dbg) st1 = __builtin_readcyclecounter();
+    asm volatile(CSM_A64_DQ_LOOP CSM_A64_DQ_OPERANDS : CSM_A64_DQ_CLOBBERS);
+#undef CSM_A64_DQ_OPERANDS
+    asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]));
+    if (dbg) st2 = __builtin_readcyclecounter();
+
+    // ---- epilogue: dQ^T registers (x 1/sqrt(hd), RoPE^T) -> LDS [q][d] (wave-private) -> whole 128-B rows of the q block of dqkv
+    char* ob = smem + QRING + wave * QSTAGING;           // (behind the ring: slower waves may still be reading tiles)
+    static_for<0, 2>([&](auto qt_) {
+        constexpr int qt = decltype(qt_)::value;
+        float t0[16], t1[16];
+        static_for<0, 16>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            t0[i] = acc_read1<16 * qt + i>() * scale;              // tile (dt = 0, qt)
+            t1[i] = acc_read1<16 * (2 + qt) + i>() * scale;        // tile (dt = 1, qt)
+        });
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float a0 = t0[4 * gq], a1 = t0[4 * gq + 1], a2 = t0[4 * gq + 2], a3 = t0[4 * gq + 3];
+            float b0 = t1[4 * gq], b1 = t1[4 * gq + 1], b2 = t1[4 * gq + 2], b3 = t1[4 * gq + 3];
+            if (rope) {
+                const float4 t = rt[qt][gq][0], u = rt[qt][gq][1];
+                const float x0 = a0 * t.x + a1 * t.y, x1 = a1 * t.x - a0 * t.y, x2 = a2 * t.z + a3 * t.w, x3 = a3 * t.z - a2 * t.w;
+                const float y0 = b0 * u.x + b1 * u.y, y1 = b1 * u.x - b0 * u.y, y2 = b2 * u.z + b3 * u.w, y3 = b3 * u.z - b2 * u.w;
+                a0 = x0; a1 = x1; a2 = x2; a3 = x3; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
+            }
+            uint2 w0, w1;
+            w0.x = pack2bf(a0, a1); w0.y = pack2bf(a2, a3);
+            w1.x = pack2bf(b0, b1); w1.y = pack2bf(b2, b3);
+            *reinterpret_cast<uint2*>(ob + qt * 4608 + r * 144 + (8 * gq + 4 * h) * 2) = w0;
+            *reinterpret_cast<uint2*>(ob + qt * 4608 + r * 144 + (32 + 8 * gq + 4 * h) * 2) = w1;
+        }
+        // (wave-private LDS region: a wave's own LDS operations execute in order)
+        bf16_t* dst = dqkv + ((size_t)b * S + q0 + 32 * qt) * ld + hq * 64;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = 8 * pass + (lane >> 3);
+            const U4 v = *reinterpret_cast<const U4*>(ob + qt * 4608 + row * 144 + (lane & 7) * 16);
+            *reinterpret_cast<U4*>(dst + (size_t)row * ld + (lane & 7) * 8) = v;
+        }
+    });
+    if (dbg && lane == 0) {                              // per (workgroup, wave, round): stream length, cycle stamps, 100 MHz stamps
+        unsigned long long* d = dbg + (((size_t)blockIdx.x * 4 + wave) * 8 + round) * 8;
+        d[0] = ntiles; d[1] = st0; d[2] = st1; d[3] = st2; d[4] = __builtin_readcyclecounter(); d[5] = rt0; d[6] = __builtin_amdgcn_s_memrealtime(); d[7] = ((sta - st0) << 32) | (stb - st0);
+    }
+  }
+}
+
 }  // namespace
 
 // 1 = taken, 0 = shape not supported (the caller falls back to attention64.hip's kernel)
@@ -187,5 +369,29 @@ int csm_attn64_dkv_asm_launch(const void* qkv, const void* dout, const float* st
     dim3 grid((unsigned)((S / 64) * KV * B)), block(256);
     hipLaunchKernelGGL(attn64_dkv_asm_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, stats, (bf16_t*)dqkv, S, H,
                        KV, scale, rope, (long long)B * H * S, c2bits, g_attn64_dkv_asm_order);
+    return 1;
+}
+
+int g_attn64_dq_asm_order = 0;
+unsigned long long* g_attn64_dq_dbg = nullptr;       // csm_attn64_set_debug (tools/probes)
+extern "C" int csm_attn64_set_debug(void* p) { g_attn64_dq_dbg = (unsigned long long*)p; return 0; }
+// 1 = taken, 0 = shape not supported (the caller falls back to attention64.hip's dQ kernel)
+int csm_attn64_dq_asm_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* stats, void* dqkv, int B, int S,
+                             int H, int KV, const float* rope, hipStream_t stream) {
+    if (S % 64 != 0 || S < 64 || H != 4 * KV) return 0;
+    const float scale = 0.125f, c2 = scale * 1.4426950408889634f;
+    unsigned c2bits;
+    memcpy(&c2bits, &c2, 4);
+    const int lds = QRING + 4 * QSTAGING;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)attn64_dq_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+    // query blocks per round: enough workgroups for every CU (256) when the batch allows, each then walking nq / levels blocks
+    const int P = KV * B, nq = S / 64;
+    int levels = g_attn64_dq_asm_order ? nq : (256 + P - 1) / P;
+    if (levels > nq) levels = nq;
+    if (levels < 1) levels = 1;
+    dim3 grid((unsigned)(P * levels)), block(256);
+    hipLaunchKernelGGL(attn64_dq_asm_kernel, grid, block, lds, stream, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, stats,
+                       (bf16_t*)dqkv, S, H, KV, scale, rope, (long long)B * H * S, c2bits, levels, g_attn64_dq_dbg);
     return 1;
 }

@@ -146,10 +146,13 @@ int csm_attn_bwd(const void* qkv, const void* out, const void* dout, const float
  * inside the sequence): dqkv comes out as the gradient of the UN-rotated projection output, no separate inverse pass. */
 int csm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
                       const float* rope_table, int B, int S, int H, int KV, int HD, csm_stream_t stream);
-/* which dK / dV kernel the most recent csm_attn_bwd* call on this library instance launched (for tests and benchmarks; not
- * thread-safe; since ABI 3): 1 = the generated-asm kernel of attention64_asm.hip (head_dim 64, S % 64 == 0, 4 query heads per
- * kv head), 0 = the compiler-scheduled kernel of attention64.hip / attention.hip */
+/* which kernels the most recent csm_attn_bwd* call on this library instance launched (for tests and benchmarks; not
+ * thread-safe; since ABI 3): bit 0 = the dK/dV pass, bit 1 = the dQ pass ran the generated-asm kernel of attention64_asm.hip
+ * (head_dim 64, S % 64 == 0, 4 query heads per kv head); a clear bit = the compiler-scheduled kernel of attention64.hip /
+ * attention.hip */
 int csm_attn_last_dkv_kernel(void);
+/* tools/probes only: a device buffer (>= grid x 4 waves x 8 rounds x 8 u64) that the asm dQ kernel fills with cycle stamps, or NULL */
+int csm_attn64_set_debug(void* device_buffer);
 
 /* ---- K7: SwiGLU of torchtune FeedForward: out = silu(gate) * up, gu = gate/up INTERLEAVED ([M][2F]: g0,u0,g1,u1,..) - */
 int csm_swiglu_fwd(const void* gu, void* out, long long M, int F, csm_stream_t stream);

@@ -963,9 +963,9 @@ def test_gemm_four_wave_kernel_fused_epilogues(dev):
 
 
 @pytest.mark.parametrize("B,S,H,KV", [(1, 64, 4, 1), (1, 128, 4, 1), (2, 192, 8, 2), (1, 512, 8, 2), (2, 320, 4, 1), (1, 2048, 8, 2)])
-def test_attention_dkv_generated_asm_kernel(dev, B, S, H, KV):
-    """attention64_asm.hip (round 4): the dK/dV pass as one wave per (64 keys, query head) with a generated, hand-allocated asm
-    loop.  Against the fp32 oracle (same tolerance as test_attention), against the second-generation kernel it replaces
+def test_attention_backward_generated_asm_kernels(dev, B, S, H, KV):
+    """attention64_asm.hip (round 4): the dK/dV pass as one wave per (64 keys, query head) and the dQ pass as one wave per (64
+    queries, query head), each with a generated, hand-allocated asm loop.  Against the fp32 oracle (same tolerance as test_attention), against the second-generation kernel it replaces
     (csm_set_attn_variant bit 10 switches it off: the two differ only in the order the four heads / two parities are summed),
     with and without the RoPE^T epilogue, both work orders (bit 11), and bit-identical from run to run."""
     from csm.hip import ops
@@ -987,7 +987,7 @@ def test_attention_dkv_generated_asm_kernel(dev, B, S, H, KV):
     DEFAULTS = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7)
     res = {}
     try:
-        for name, v in (("gen2", DEFAULTS | (1 << 10)), ("asm", 0), ("asm_pairs", DEFAULTS | (1 << 11)), ("asm_again", 0)):
+        for name, v in (("gen2", DEFAULTS | (1 << 10) | (1 << 12)), ("asm", 0), ("asm_pairs", DEFAULTS | (1 << 11)), ("asm_again", 0)):
             ops.lib.csm_set_attn_variant(v)
             for rope in (None, table):
                 dqkv = torch.full_like(qd, float("nan"))
@@ -995,11 +995,12 @@ def test_attention_dkv_generated_asm_kernel(dev, B, S, H, KV):
                 res[name, rope is not None] = dqkv.clone()
     finally:
         ops.lib.csm_set_attn_variant(0)
-    assert ops.lib.csm_attn_last_dkv_kernel() == 1, "the asm kernel must have taken this shape"
+    assert ops.lib.csm_attn_last_dkv_kernel() == 3, "the asm kernels (dK/dV and dQ) must have taken this shape"
+    close("asm dq", res["asm", False][:, :H * hd], gq[:, :H * hd], 2e-2)
     close("asm dk", res["asm", False][:, H * hd:(H + KV) * hd], gq[:, H * hd:(H + KV) * hd], 2e-2)
     close("asm dv", res["asm", False][:, (H + KV) * hd:], gq[:, (H + KV) * hd:], 2e-2)
     for rope in (False, True):
         assert not torch.isnan(res["asm", rope].float()).any()
-        close("asm vs second generation", res["asm", rope][:, kv], res["gen2", rope][:, kv].float(), 2e-3)
+        close("asm vs second generation", res["asm", rope], res["gen2", rope].float(), 2e-3)
         assert torch.equal(res["asm", rope], res["asm_again", rope]), "run-to-run bit-identical"
         assert torch.equal(res["asm", rope], res["asm_pairs", rope]), "the work order must not change a bit"
