@@ -174,13 +174,17 @@ __global__ __launch_bounds__(256, 1) void attn64_dkv_asm_kernel(const bf16_t* __
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// dQ pass, same construction (tools/gen/gen_attn64_dq_loop.py): one wave = 64 queries (two 32-query tiles, the query on the
+// dQ pass, same construction (tools/gen/gen_attn64_dq_loop.py): one wave = 128 queries (four 32-query tiles, the query on the
 // lane) of one query head, its Q^T / dO^T operands in AGPRs, walking the 32-key tiles from the diagonal down to key 0.  The four
-// waves of a workgroup are the four query heads of one GQA group on the same 64-query block: they consume the same K / V tiles,
-// so the workgroup shares ONE eight-stage ring, each wave fetching a quarter of every tile, one barrier per tile.  Also computes delta = rowsum(dO o O) and publishes -delta and
-// -lse * log2(e) for the dK/dV pass, and applies the RoPE backward in the epilogue (rope != null) - as attn64_dq_kernel does.
+// waves of a workgroup are the four query heads of one GQA group on the same 128-query block: they consume the same K / V tiles,
+// so the workgroup shares ONE eight-stage ring, each wave fetching a quarter of every tile, one barrier per tile.  Persistent:
+// a workgroup keeps its (batch, kv head) pair and walks query blocks in a serpentine over the rounds, so that every workgroup's
+// total stream length is the same.  Also computes delta = rowsum(dO o O) and publishes -delta and -lse * log2(e) for the dK/dV
+// pass, and applies the RoPE backward in the epilogue (rope != null) - as attn64_dq_kernel does.
+constexpr int QNQ = CSM_A64_DQ_NQ;
 constexpr int QRING = CSM_A64_DQ_STAGE * CSM_A64_DQ_NSTAGE;      // the workgroup's K / V ring: 64 KiB
-constexpr int QSTAGING = 2 * 32 * 144;                          // per wave, behind the ring: its two 32-query dQ tiles as [q][d] rows
+constexpr int QSTAGING = 2 * CSM_A64_DQ_SG_TILE;               // per wave, behind the ring: the Q / dO / O rows of 64 queries at a time
+                                                                // on the way in, its 32-query dQ tiles as [q][d] rows on the way out
 
 __device__ __forceinline__ float halves_sum(float x) {          // lanes l and l ^ 32 hold the same query
     auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -194,11 +198,10 @@ __global__ __launch_bounds__(256, 1) void attn64_dq_asm_kernel(const bf16_t* __r
                                                                int levels /* query blocks per round of the persistent schedule */,
                                                                unsigned long long* __restrict__ dbg /* tools/probes: cycle stamps, or null */) {
     extern __shared__ __attribute__((aligned(128))) char smem[];
-    const int nqblk = S / 64;
+    const int nqblk = S / (32 * QNQ);
     // Persistent schedule: workgroup w = (pair = w % P, level = w / P) keeps its (batch, kv head) pair - its XCD keeps that pair's
     // K / V in L2 - and walks the query blocks nq-1-(L r + level') for r = 0, 1, ...: level' = level in even rounds, L-1-level in
-    // odd ones, so every workgroup gets the same total stream length (the per-workgroup fixed cost - dispatch, first loads,
-    // epilogue - is paid once per workgroup instead of once per block when the rounds are real loop trips).
+    // odd ones, so every workgroup gets the same total stream length.
     const int P = gridDim.x / levels;
     const int pair = blockIdx.x % P, level = blockIdx.x / P;
     const int kvh = pair % KV, b = pair / KV;
@@ -210,10 +213,10 @@ __global__ __launch_bounds__(256, 1) void attn64_dq_asm_kernel(const bf16_t* __r
     const int jb = nqblk - 1 - (round * levels + ((round & 1) ? levels - 1 - level : level));
     if (jb < 0) continue;                                 // (uniform over the workgroup)
     if (round) __syncthreads();                           // the ring is free again: every wave has left the previous block's loop
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0, sta = 0, stb = 0;
     if (dbg) { st0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    const int q0 = jb * 64;
-    const int ntiles = __builtin_amdgcn_readfirstlane(2 * jb + 2);             // 32-key tiles at or below the block's diagonal
+    const int q0 = jb * (32 * QNQ);
+    const int ntiles = __builtin_amdgcn_readfirstlane(QNQ * jb + QNQ);         // 32-key tiles at or below the block's diagonal
 
     const unsigned sbase = (unsigned)(uintptr_t)smem;                            // the ring is the workgroup's
     const unsigned wbase = __builtin_amdgcn_readfirstlane(sbase + (unsigned)wave * 1024u);   // this wave writes piece `wave` of every image
@@ -224,109 +227,93 @@ __global__ __launch_bounds__(256, 1) void attn64_dq_asm_kernel(const bf16_t* __r
         const int row = 4 * (g >> 1) + q4, ch = 2 * (g & 1) + (p >> 1);
         toff00 = sbase + row * 128 + ((ch ^ swz(row)) << 4) + (p & 1) * 8;
     }
-    unsigned dk[2], qo[2], oo[2];
+    unsigned dk0;
     {
         const int row = 8 * wave + (lane >> 3);                                // rows 8 wave .. 8 wave + 7 of a tile
-        dk[0] = (unsigned)(row * ld + (((lane & 7) ^ swz(row)) << 3)) * 2u;
-        dk[1] = 0;
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        qo[p] = (unsigned)((q0 + 32 * p + r) * ld + 8 * h) * 2u;           // (p = query tile)
-        oo[p] = (unsigned)((q0 + 32 * p + r) * ldo + 8 * h) * 2u;
+        dk0 = (unsigned)(row * ld + (((lane & 7) ^ swz(row)) << 3)) * 2u;
     }
     const int m0v = r - 4 * h;
     const char* Kb = reinterpret_cast<const char*>(qkv + (size_t)b * S * ld + (H + kvh) * 64);
     const char* Vb = reinterpret_cast<const char*>(qkv + (size_t)b * S * ld + (H + KV + kvh) * 64);
-    const char* Qb = reinterpret_cast<const char*>(qkv + (size_t)b * S * ld + hq * 64);
-    const char* Ob = reinterpret_cast<const char*>(dout + (size_t)b * S * ldo + hq * 64);
-    const unsigned kstep = 32u * ld * 2u;
-
-#define CSM_A64_DQ_OPERANDS                                                                                              \
-    ::"v"(roff0), "v"(toff00), "v"(dk[0]), "v"(dk[1]), "v"(qo[0]), "v"(qo[1]), "v"(oo[0]), "v"(oo[1]), "v"(nd[0]), "v"(nd[1]),       \
-        "v"(nl[0]), "v"(nl[1]), "v"(m0v), "s"(Kb), "s"(Vb), "s"(Qb), "s"(Ob), "s"(ntiles), "s"(wbase), "s"(kstep), "s"(c2)
-    // block 1: every request the loop starts from (Q^T / dO^T operands -> AGPRs, this wave's pieces of the first tiles), no wait:
-    // the delta computation's and the RoPE table's loads below overlap them
-    float nd[2] = {0.f, 0.f}, nl[2] = {0.f, 0.f};
-    asm volatile(CSM_A64_DQ_PRO CSM_A64_DQ_OPERANDS : CSM_A64_DQ_PRO_CLOBBERS);
-    unsigned long long sta = 0, stb = 0;
-    if (dbg) sta = __builtin_readcyclecounter();
-
-    // ---- delta = rowsum(dO o O) and the exp2 addend of this lane's two queries; published for the dK/dV pass
+    // the block's first Q / dO / O row (the prologue's LDS-DMA descriptors)
+    const char* Qb = reinterpret_cast<const char*>(qkv + ((size_t)b * S + q0) * ld + hq * 64);
+    const char* Ob = reinterpret_cast<const char*>(dout + ((size_t)b * S + q0) * ldo + hq * 64);
+    const char* Pb = reinterpret_cast<const char*>(out + ((size_t)b * S + q0) * ldo + hq * 64);
+    const unsigned kstep = 32u * ld * 2u, ostep = 32u * ldo * 2u;
+    // staging area of this wave (behind the ring) and its lane addresses / LDS-DMA lane offsets
+    const unsigned sgb = __builtin_amdgcn_readfirstlane(sbase + QRING + (unsigned)wave * QSTAGING);
+    const unsigned sgoff = sgb + r * 128 + ((h ^ swz(r)) << 4);
+    unsigned dqo[2], doo[2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = q0 + 32 * qt + r;
-        const bf16_t* op = out + ((size_t)b * S + q) * ldo + hq * 64 + 8 * h;
-        const bf16_t* dp = dout + ((size_t)b * S + q) * ldo + hq * 64 + 8 * h;
-        float dsum = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dp + 16 * ks);
-            const bf16x8 of = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dsum += bf2f((bf16_t)dof[j]) * bf2f((bf16_t)of[j]);
-        }
-        nd[qt] = -halves_sum(dsum);
-        nl[qt] = -lse[((size_t)b * H + hq) * S + q] * 1.4426950408889634f;
-        if (h == 0) {
-            stats[((size_t)b * H + hq) * S + q] = nd[qt];
-            stats[(size_t)nstat + ((size_t)b * H + hq) * S + q] = nl[qt];
-        }
+    for (int p = 0; p < 2; ++p) {
+        const int row = 8 * p + (lane >> 3);
+        dqo[p] = (unsigned)(row * ld + (((lane & 7) ^ swz(row)) << 3)) * 2u;
+        doo[p] = (unsigned)(row * ldo + (((lane & 7) ^ swz(row)) << 3)) * 2u;
     }
-
-    if (dbg) stb = __builtin_readcyclecounter();
-    // RoPE table entries of this lane's two queries, requested before the loop and used after it
-    float4 rt[2][4][2];
+    float nd[QNQ] = {0.f, 0.f, 0.f, 0.f}, nl[QNQ] = {0.f, 0.f, 0.f, 0.f};
+#define CSM_A64_DQ_OPERANDS                                                                                              \
+    ::"v"(roff0), "v"(toff00), "v"(dk0), "v"(sgoff), "v"(dqo[0]), "v"(nd[0]), "v"(nd[1]), "v"(nd[2]), "v"(nd[3]), "v"(nl[0]), "v"(nl[1]),  \
+        "v"(nl[2]), "v"(nl[3]), "v"(m0v), "s"(Kb), "s"(Vb), "s"(Qb), "s"(Ob), "s"(ntiles), "s"(wbase), "s"(kstep), "s"(c2), "s"(ostep),   \
+        "v"(dqo[1]), "v"(doo[0]), "v"(doo[1]), "s"(Pb), "s"(sgb)
+    // delta = rowsum(dO o O) and the exp2 addend of the lane's queries of tiles 2 half, 2 half + 1, from the staged rows;
+    // published for the dK/dV pass
+    auto delta_half = [&](int half) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+        for (int j = 0; j < 2; ++j) {
+            const int qt = 2 * half + j;
+            const int q = q0 + 32 * qt + r;
+            const char* img = smem + (sgb - sbase) + j * CSM_A64_DQ_SG_TILE + r * 128;
+            float dsum = 0.f;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            rt[qt][gq][0] = rt[qt][gq][1] = make_float4(1.f, 0.f, 1.f, 0.f);
-            if (rope) {
-                const float* tr = rope + ((size_t)(q0 + 32 * qt + r) * 32 + 4 * gq + 2 * h) * 2;
-                rt[qt][gq][0] = *reinterpret_cast<const float4*>(tr);
-                rt[qt][gq][1] = *reinterpret_cast<const float4*>(tr + 32);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = ((2 * ks + h) ^ swz(r)) << 4;
+                const bf16x8 dof = *reinterpret_cast<const bf16x8*>(img + 4096 + ch);
+                const bf16x8 of = *reinterpret_cast<const bf16x8*>(img + 8192 + ch);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dsum += bf2f((bf16_t)dof[e]) * bf2f((bf16_t)of[e]);
+            }
+            const float d_ = -halves_sum(dsum);
+            const float l_ = -lse[((size_t)b * H + hq) * S + q] * 1.4426950408889634f;
+            if (qt == 0) { nd[0] = d_; nl[0] = l_; } else if (qt == 1) { nd[1] = d_; nl[1] = l_; }
+            else if (qt == 2) { nd[2] = d_; nl[2] = l_; } else { nd[3] = d_; nl[3] = l_; }
+            if (h == 0) {
+                stats[((size_t)b * H + hq) * S + q] = d_;
+                stats[(size_t)nstat + ((size_t)b * H + hq) * S + q] = l_;
             }
         }
-
-    // The NEXT block's Q / dO / O rows (one 128-B line per row and tensor, cold in HBM: fetched by every CU at once they cost
-    // ~12k cycles in front of the loop - the prologue burst runs at the HBM rate, ~11 B/cycle/CU): one dword per line requested
-    // now brings them into this XCD's L2 while the loop runs.  Lane = row of the next 64-query block; results unused.
-    unsigned touch[3] = {0u, 0u, 0u};
-    {
-        const int nr = round + 1;
-        const int jn = nqblk - 1 - (nr * levels + ((nr & 1) ? levels - 1 - level : level));
-        if (jn >= 0) {
-            const size_t row = (size_t)b * S + jn * 64 + lane;
-            // (inline asm: a load the compiler knows about is waited for in front of the loop block; the registers stay reserved
-            //  until the empty asm behind the loop names them)
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch[0]) : "v"(qkv + row * ld + hq * 64));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch[1]) : "v"(dout + row * ldo + hq * 64));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch[2]) : "v"(out + row * ldo + hq * 64));
-        }
-    }
-    if (dbg) st1 = __builtin_readcyclecounter();
+    };
+    // Prologue: the wave's Q / dO / O rows arrive as whole 128-B rows by LDS-DMA, 64 queries at a time (the first version's
+    // per-lane fragment loads - 32 rows per request, a quarter of each line used - took 11k cycles to issue, and as many again
+    // for the delta computation's); this wave's pieces of the first key tiles ride with the first half.
+    asm volatile(CSM_A64_DQ_STAGE0 CSM_A64_DQ_OPERANDS : CSM_A64_DQ_PRO_CLOBBERS);
+    if (dbg) sta = __builtin_readcyclecounter();
+    asm volatile(CSM_A64_DQ_LAND0 CSM_A64_DQ_OPERANDS : CSM_A64_DQ_PRO_CLOBBERS);
+    delta_half(0);
+    asm volatile(CSM_A64_DQ_STAGE1 CSM_A64_DQ_OPERANDS : CSM_A64_DQ_PRO_CLOBBERS);
+    asm volatile(CSM_A64_DQ_LAND1 CSM_A64_DQ_OPERANDS : CSM_A64_DQ_PRO_CLOBBERS);
+    delta_half(1);
+    if (dbg) { stb = __builtin_readcyclecounter(); st1 = stb; }
     asm volatile(CSM_A64_DQ_LOOP CSM_A64_DQ_OPERANDS : CSM_A64_DQ_CLOBBERS);
 #undef CSM_A64_DQ_OPERANDS
-    asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]));
     if (dbg) st2 = __builtin_readcyclecounter();
 
     // ---- epilogue: dQ^T registers (x 1/sqrt(hd), RoPE^T) -> LDS [q][d] (wave-private) -> whole 128-B rows of the q block of dqkv
-    char* ob = smem + QRING + wave * QSTAGING;           // (behind the ring: slower waves may still be reading tiles)
-    static_for<0, 2>([&](auto qt_) {
+    char* ob = smem + QRING + wave * QSTAGING;           // (the wave's staging area behind the ring: slower waves may still be reading tiles)
+    static_for<0, QNQ>([&](auto qt_) {
         constexpr int qt = decltype(qt_)::value;
         float t0[16], t1[16];
         static_for<0, 16>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             t0[i] = acc_read1<16 * qt + i>() * scale;              // tile (dt = 0, qt)
-            t1[i] = acc_read1<16 * (2 + qt) + i>() * scale;        // tile (dt = 1, qt)
+            t1[i] = acc_read1<16 * (QNQ + qt) + i>() * scale;      // tile (dt = 1, qt)
         });
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             float a0 = t0[4 * gq], a1 = t0[4 * gq + 1], a2 = t0[4 * gq + 2], a3 = t0[4 * gq + 3];
             float b0 = t1[4 * gq], b1 = t1[4 * gq + 1], b2 = t1[4 * gq + 2], b3 = t1[4 * gq + 3];
             if (rope) {
-                const float4 t = rt[qt][gq][0], u = rt[qt][gq][1];
+                const float* tr = rope + ((size_t)(q0 + 32 * qt + r) * 32 + 4 * gq + 2 * h) * 2;
+                const float4 t = *reinterpret_cast<const float4*>(tr), u = *reinterpret_cast<const float4*>(tr + 32);
                 const float x0 = a0 * t.x + a1 * t.y, x1 = a1 * t.x - a0 * t.y, x2 = a2 * t.z + a3 * t.w, x3 = a3 * t.z - a2 * t.w;
                 const float y0 = b0 * u.x + b1 * u.y, y1 = b1 * u.x - b0 * u.y, y2 = b2 * u.z + b3 * u.w, y3 = b3 * u.z - b2 * u.w;
                 a0 = x0; a1 = x1; a2 = x2; a3 = x3; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
@@ -348,7 +335,8 @@ __global__ __launch_bounds__(256, 1) void attn64_dq_asm_kernel(const bf16_t* __r
     });
     if (dbg && lane == 0) {                              // per (workgroup, wave, round): stream length, cycle stamps, 100 MHz stamps
         unsigned long long* d = dbg + (((size_t)blockIdx.x * 4 + wave) * 8 + round) * 8;
-        d[0] = ntiles; d[1] = st0; d[2] = st1; d[3] = st2; d[4] = __builtin_readcyclecounter(); d[5] = rt0; d[6] = __builtin_amdgcn_s_memrealtime(); d[7] = ((sta - st0) << 32) | (stb - st0);
+        d[0] = ntiles; d[1] = st0; d[2] = st1; d[3] = st2; d[4] = __builtin_readcyclecounter(); d[5] = rt0; d[6] = __builtin_amdgcn_s_memrealtime();
+        d[7] = ((sta - st0) << 32) | (stb - st0);
     }
   }
 }
@@ -378,7 +366,7 @@ extern "C" int csm_attn64_set_debug(void* p) { g_attn64_dq_dbg = (unsigned long 
 // 1 = taken, 0 = shape not supported (the caller falls back to attention64.hip's dQ kernel)
 int csm_attn64_dq_asm_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* stats, void* dqkv, int B, int S,
                              int H, int KV, const float* rope, hipStream_t stream) {
-    if (S % 64 != 0 || S < 64 || H != 4 * KV) return 0;
+    if (S % (32 * QNQ) != 0 || S < 32 * QNQ || H != 4 * KV) return 0;
     const float scale = 0.125f, c2 = scale * 1.4426950408889634f;
     unsigned c2bits;
     memcpy(&c2bits, &c2, 4);
@@ -386,7 +374,7 @@ int csm_attn64_dq_asm_launch(const void* qkv, const void* out, const void* dout,
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void*)attn64_dq_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
     // query blocks per round: enough workgroups for every CU (256) when the batch allows, each then walking nq / levels blocks
-    const int P = KV * B, nq = S / 64;
+    const int P = KV * B, nq = S / (32 * QNQ);
     int levels = g_attn64_dq_asm_order ? nq : (256 + P - 1) / P;
     if (levels > nq) levels = nq;
     if (levels < 1) levels = 1;
