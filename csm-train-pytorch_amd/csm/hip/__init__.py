@@ -97,6 +97,8 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.restype = _res
 
 EXPORTS = tuple(_SIGS)
+if os.environ.get("CSM_ATTN_VARIANT"):                  # kernel A/B only (tools/probes): csm_set_attn_variant word
+    lib.csm_set_attn_variant(int(os.environ["CSM_ATTN_VARIANT"], 0))
 if os.environ.get("CSM_GEMM256_PERSISTENT") == "0":     # kernel A/B only (tools/probes)
     lib.csm_set_gemm256_persistent(0)
 if os.environ.get("CSM_GEMM_TOUCH") == "0":             # kernel A/B only (tools/probes)

@@ -598,7 +598,10 @@ int csm_attn64_dkv_asm_launch(const void* qkv, const void* dout, const float* st
 extern int g_attn64_dkv_asm_order, g_attn64_dq_asm_order;
 int csm_attn64_dq_asm_launch(const void* qkv, const void* out, const void* dout, const float* lse, float* stats, void* dqkv, int B, int S,
                              int H, int KV, const float* rope, hipStream_t stream);
-static int g_attn_last_dkv = 0, g_attn_last_dq = 0, g_attn_dq_asm = 1;
+// The asm dQ kernel is OFF by default: isolated it beats the compiler-scheduled one (122 vs 134 us at B=4, S=2048, 32/8 heads),
+// inside the train step it does not (130.6 vs 128.1 us, profiles/r04_step_attention_kernels.txt): with one wave per SIMD nothing
+// covers the moment at which all 256 workgroups fetch their Q / dO / O rows at once.  csm_set_attn_variant bit 12 switches it on.
+static int g_attn_last_dkv = 0, g_attn_last_dq = 0, g_attn_dq_asm = 0;
 // bit 0: the dK/dV pass, bit 1: the dQ pass of the most recent csm_attn_bwd* call ran the generated-asm kernel
 extern "C" int csm_attn_last_dkv_kernel(void) { return g_attn_last_dkv | (g_attn_last_dq << 1); }
 static int g_attn_dkv_asm = 1;                       // csm_set_attn_variant bit 10 switches the asm dK/dV kernel off (A/B)
@@ -610,7 +613,8 @@ extern "C" int csm_set_attn_variant(int v) {
     // bit 6 dK/dV key tile (1: 64 keys per workgroup, 0: 128); bit 7 forward / dQ work order heaviest q-blocks first.
     // bits 8..9: 0 = second-generation head_dim-64 kernels (attention64.hip; the default), 1 = first generation forward,
     // 2 = first generation backward, 3 = both first generation (A/B reference).  bit 10: dK/dV through attention64.hip's
-    // second-generation kernel instead of the generated-asm one of attention64_asm.hip.
+    // second-generation kernel instead of the generated-asm one of attention64_asm.hip; bit 11: that kernel pair by pair;
+    // bit 12: dQ through the generated-asm kernel (off by default); bit 13: that kernel one query block per workgroup.
     if (v == 0) v = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7);
     g_attn_gen2 = 3 & ~((v >> 8) & 3);
     g_attn_qt_fwd = (v & 3) == 2 ? 2 : 1;
@@ -619,7 +623,7 @@ extern "C" int csm_set_attn_variant(int v) {
     g_attn_dkv_kt1 = (v >> 6) & 1;
     g_attn_q_lpt = (v >> 7) & 1;
     g_attn_dkv_asm = !((v >> 10) & 1);               // bit 10: second-generation dK/dV kernel instead of the asm one
-    g_attn_dq_asm = !((v >> 12) & 1);                // bit 12: second-generation dQ kernel instead of the asm one
+    g_attn_dq_asm = (v >> 12) & 1;                   // bit 12: the asm dQ kernel instead of the second-generation one (see above)
     g_attn64_dq_asm_order = (v >> 13) & 1;           // bit 13: asm dQ kernel one query block per workgroup (not persistent)
     g_attn64_dkv_asm_order = (v >> 11) & 1;          // bit 11: asm dK/dV kernel walks an XCD's (batch, kv head) pairs one after the other
     return 0;

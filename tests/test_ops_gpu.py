@@ -988,16 +988,20 @@ def test_attention_backward_generated_asm_kernels(dev, B, S, H, KV):
     DEFAULTS = 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7)
     res = {}
     try:
-        for name, v in (("gen2", DEFAULTS | (1 << 10) | (1 << 12)), ("asm", 0), ("asm_pairs", DEFAULTS | (1 << 11)), ("asm_again", 0)):
+        DQ = 1 << 12                              # the asm dQ kernel is off by default (slower inside the step): switched on here
+        for name, v in (("gen2", DEFAULTS | (1 << 10)), ("asm", DEFAULTS | DQ), ("asm_pairs", DEFAULTS | DQ | (1 << 11) | (1 << 13)),
+                        ("asm_again", DEFAULTS | DQ), ("default", 0)):
             ops.lib.csm_set_attn_variant(v)
             for rope in (None, table):
                 dqkv = torch.full_like(qd, float("nan"))
                 ops.attn_bwd(qd, out, dd, lse, dqkv, delta, B, S, H, KV, hd, rope_table=rope)
                 res[name, rope is not None] = dqkv.clone()
+                if name == "asm_again":   # (the asm dQ kernel takes 128-query blocks: S % 128 == 0; the dK/dV one 64-key blocks)
+                    assert ops.lib.csm_attn_last_dkv_kernel() == (3 if S % 128 == 0 else 1), "the asm kernels must have taken this shape"
+                if name == "default":
+                    assert ops.lib.csm_attn_last_dkv_kernel() == 1, "default: asm dK/dV, compiler-scheduled dQ"
     finally:
         ops.lib.csm_set_attn_variant(0)
-    # (the asm dQ kernel takes 128-query blocks: S % 128 == 0; the dK/dV one 64-key blocks)
-    assert ops.lib.csm_attn_last_dkv_kernel() == (3 if S % 128 == 0 else 1), "the asm kernels must have taken this shape"
     close("asm dq", res["asm", False][:, :H * hd], gq[:, :H * hd], 2e-2)
     close("asm dk", res["asm", False][:, H * hd:(H + KV) * hd], gq[:, H * hd:(H + KV) * hd], 2e-2)
     close("asm dv", res["asm", False][:, (H + KV) * hd:], gq[:, (H + KV) * hd:], 2e-2)
@@ -1006,3 +1010,4 @@ def test_attention_backward_generated_asm_kernels(dev, B, S, H, KV):
         close("asm vs second generation", res["asm", rope], res["gen2", rope].float(), 2e-3)
         assert torch.equal(res["asm", rope], res["asm_again", rope]), "run-to-run bit-identical"
         assert torch.equal(res["asm", rope], res["asm_pairs", rope]), "the work order must not change a bit"
+        assert torch.equal(res["default", rope][:, kv], res["asm", rope][:, kv]) and torch.equal(res["default", rope][:, :H * hd], res["gen2", rope][:, :H * hd])

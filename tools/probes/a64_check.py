@@ -9,7 +9,8 @@ import torch
 from csm.hip import ops
 from oracle import csm_oracle as O
 dev = "cuda"
-OFF = 5366
+OFF = 1270          # defaults with the asm dK/dV kernel off
+ON = 246 | 4096     # defaults + the asm dQ kernel
 
 
 def run(B, S, H, KV, hd=64, seed=0, rope=False, check_ref=True):
@@ -26,14 +27,14 @@ def run(B, S, H, KV, hd=64, seed=0, rope=False, check_ref=True):
         from csm.models.model import llama3_rope_table
         table = llama3_rope_table(S, hd, 500000.0, 32.0).to(dev).contiguous()
     res = {}
-    for v in (OFF, 0, 0):
+    for v in (OFF, ON, ON):
         ops.lib.csm_set_attn_variant(v)
         dqkv = torch.full_like(qd, float("nan"))
         ops.attn_bwd(qd, out, dd, lse, dqkv, delta, B, S, H, KV, hd, rope_table=table)
         torch.cuda.synchronize()
         res.setdefault(v, []).append(dqkv.float().cpu())
     ops.lib.csm_set_attn_variant(0)
-    old, new, new2 = res[OFF][0], res[0][0], res[0][1]
+    old, new, new2 = res[OFF][0], res[ON][0], res[ON][1]
     kv = slice(0, None)
     sc = old[:, kv].abs().max().item()
     d = (old[:, kv] - new[:, kv]).abs().max().item()

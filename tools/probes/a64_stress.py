@@ -19,10 +19,10 @@ for (B, S, H, KV) in [(1, 2048, 4, 1), (4, 2048, 32, 8), (2, 256, 8, 2)]:
     delta = torch.empty(2, B, H, S, dtype=torch.float32, device=dev)
     table = llama3_rope_table(S, hd, 500000.0, 32.0).to(dev).contiguous()
     for rope in (None, table):
-        ops.lib.csm_set_attn_variant(5366)
+        ops.lib.csm_set_attn_variant(1270)
         ref = torch.zeros_like(qkv)
         ops.attn_bwd(qkv, out, dout, lse, ref, delta, B, S, H, KV, hd, rope_table=rope)
-        ops.lib.csm_set_attn_variant(0)
+        ops.lib.csm_set_attn_variant(246 | 4096)
         first, bad = None, 0
         tsum0 = table.double().sum().item()
         tclone = table.clone()
@@ -44,7 +44,7 @@ for (B, S, H, KV) in [(1, 2048, 4, 1), (4, 2048, 32, 8), (2, 256, 8, 2)]:
         dt = (table - tclone).abs()
         print(f"   {bad} of {N - 1} repeats differ; rope table changed: {bool((dt > 0).any())} (max {dt.max().item():.3e}, cols {torch.nonzero(dt.view(S, -1).max(0).values > 0).flatten()[:8].tolist()})", flush=True)
         if rope is not None:
-            ops.lib.csm_set_attn_variant(5366)
+            ops.lib.csm_set_attn_variant(1270)
             g1 = torch.zeros_like(qkv); g2 = torch.zeros_like(qkv)
             ops.attn_bwd(qkv, out, dout, lse, g1, delta, B, S, H, KV, hd, rope_table=rope)
             ops.attn_bwd(qkv, out, dout, lse, g2, delta, B, S, H, KV, hd, rope_table=rope)

@@ -11,7 +11,7 @@ dout = torch.randn(B * S, H * hd, device=dev, generator=g).to(torch.bfloat16)
 out = torch.empty(B * S, H * hd, dtype=torch.bfloat16, device=dev)
 lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
 dqkv = torch.empty_like(qkv); delta = torch.empty(2, B, H, S, dtype=torch.float32, device=dev)
-for v in (5366, 0, 246 | 8192):
+for v in (1270, 0, 246 | 4096):
     ops.lib.csm_set_attn_variant(v)
     for _ in range(20):
         ops.attn_fwd(qkv, out, lse, B, S, H, KV, hd)
