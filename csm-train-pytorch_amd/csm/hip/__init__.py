@@ -54,6 +54,7 @@ _SIGS = {
     "csm_set_attn_variant": ([_i], _i),
     "csm_attn_last_dkv_kernel": ([], _i),
     "csm_attn64_set_debug": ([_p], _i),
+    "csm_set_decode_tuning": ([_i, _i], _i),
     "csm_attn_fwd": ([_p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_bwd_rope": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
@@ -99,6 +100,9 @@ for _name, (_args, _res) in _SIGS.items():
 EXPORTS = tuple(_SIGS)
 if os.environ.get("CSM_ATTN_VARIANT"):                  # kernel A/B only (tools/probes): csm_set_attn_variant word
     lib.csm_set_attn_variant(int(os.environ["CSM_ATTN_VARIANT"], 0))
+if os.environ.get("CSM_DECODE_TUNING"):                 # "reg,nt" e.g. "0,1": kernel A/B only (tools/probes)
+    for _k, _v in enumerate(os.environ["CSM_DECODE_TUNING"].split(",")):
+        lib.csm_set_decode_tuning(_k, int(_v))
 if os.environ.get("CSM_GEMM256_PERSISTENT") == "0":     # kernel A/B only (tools/probes)
     lib.csm_set_gemm256_persistent(0)
 if os.environ.get("CSM_GEMM_TOUCH") == "0":             # kernel A/B only (tools/probes)

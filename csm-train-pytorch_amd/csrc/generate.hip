@@ -303,6 +303,86 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
     }
 }
 
+// The same product for ONE batch row with x held in REGISTERS by every wave (round 4): K = 512 KCH, lane l owns the chunks
+// k = 8 l + 512 c, c < KCH - the very chunks it multiplies in gemv_kernel's loop - so the whole of x is in the wave (KCH 16-byte
+// loads per lane, L2 hits) and the RMSNorm prologue is a wave reduction: no LDS copy of x, no workgroup barrier (gemv_kernel has
+// three in front of its first weight load), and the wave's weight rows are requested before anything else.  Same arithmetic
+// in the same order as gemv_kernel<1, ...> (bit-identical: tests/test_e2e_gpu.py decode checks).  NT: non-temporal weight loads
+// for matrices that are streamed once per frame (the backbone's 1.9 GB), so that they do not push the depth decoder's 222 MB -
+// re-read 31 times per frame - out of the Infinity Cache.
+template <int KCH, typename OutT, bool SWIGLU, bool NT>
+__global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
+                                                       const bf16_t* __restrict__ R, int N, int ldw, int ldx, int ldy,
+                                                       const bf16_t* __restrict__ norm_w, float eps, const int* __restrict__ row_index,
+                                                       int row_offset) {
+    constexpr int K = 512 * KCH;
+    constexpr int RW = SWIGLU ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int NO = N / RW;
+    if (n >= NO) return;
+    // the wave's weight row(s): requested first
+    U4 wq[RW][KCH];
+    const bf16_t* w = W + (size_t)n * RW * ldw + lane * 8;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const U4* p = reinterpret_cast<const U4*>(w + (size_t)r * ldw + 512 * c);
+            wq[r][c] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+    const size_t row = row_index ? (size_t)(row_index[0] + row_offset) : (size_t)0;
+    U4 xq[KCH];
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) xq[c] = *reinterpret_cast<const U4*>(x + row * ldx + lane * 8 + 512 * c);
+    if (norm_w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            float f[8];
+            unpack8(xq[c], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)K + eps);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            float f[8], w8[8];
+            unpack8(xq[c], f);
+            unpack8(*reinterpret_cast<const U4*>(norm_w + lane * 8 + 512 * c), w8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = f[j] * rs * w8[j];
+            xq[c] = pack8(f);
+        }
+    }
+    float acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        float xf[8];
+        unpack8(xq[c], xf);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            float wf[8];
+            unpack8(wq[r][c], wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r] += wf[j] * xf[j];
+        }
+    }
+    float v = wave_sum(acc[0]);
+    if constexpr (SWIGLU) {
+        const float g = bf2f(f2bf(v)), u = bf2f(f2bf(wave_sum(acc[1])));
+        v = silu(g) * u;
+    }
+    if (lane == 0) {
+        if (R) v += bf2f(R[n]);
+        if constexpr (sizeof(OutT) == 2) y[n] = f2bf(v);
+        else y[n] = v;
+    }
+}
+
 // y[b][n] = sum_k x[b][k] * W[k][n]  (weights stored K-major, e.g. audio_head[i] = [d'][V]): a thread owns 8 columns.
 template <int NB, typename OutT>
 __global__ __launch_bounds__(256) void gemv_t_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
@@ -582,6 +662,11 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+static int g_gemv_reg = 1, g_gemv_nt = 1;       // csm_set_decode_tuning (A/B: tools/probes)
+extern "C" int csm_set_decode_tuning(int key, int value) {
+    if (key == 0) g_gemv_reg = value; else if (key == 1) g_gemv_nt = value; else return 1;
+    return 0;
+}
 static int gemv_launch(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
                        int out_f32, const void* norm_w, float eps, int swiglu, const int* row_index, int row_offset,
                        hipStream_t stream) {
@@ -590,6 +675,21 @@ static int gemv_launch(const void* x, const void* W, void* y, const void* residu
     CSM_REQUIRE((size_t)B * K * 2 <= 65536, "csm_gemv_bf16: B*K too large for the LDS copy of x");
     CSM_REQUIRE(!swiglu || ((N & 1) == 0 && !out_f32), "csm_gemv_bf16_ex: the SwiGLU form needs an even N and bf16 output");
     const int no = swiglu ? N / 2 : N;
+    if (B == 1 && g_gemv_reg && (K == 1024 || K == 2048 || K == 8192)) {
+        // one batch row: x in registers, no LDS, no barrier (gemv_reg_kernel); matrices of the 2048-wide stack are streamed once
+        // per frame: non-temporal
+        const int grid = (no + 3) / 4;
+        const bool nt = g_gemv_nt && (K == 2048 || (K == 8192 && N == 2048));
+#define LR(KCH, T, SW, NT_) hipLaunchKernelGGL((gemv_reg_kernel<KCH, T, SW, NT_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset)
+#define LK(T, SW, NT_) do { if (K == 1024) LR(2, T, SW, NT_); else if (K == 2048) LR(4, T, SW, NT_); else LR(16, T, SW, NT_); } while (0)
+        if (swiglu) { if (nt) LK(bf16_t, true, true); else LK(bf16_t, true, false); }
+        else if (out_f32) { if (nt) LK(float, false, true); else LK(float, false, false); }
+        else { if (nt) LK(bf16_t, false, true); else LK(bf16_t, false, false); }
+#undef LK
+#undef LR
+        CSM_CHECK_LAUNCH("csm_gemv_bf16");
+        return 0;
+    }
     const int grid = no / 4 < 1 ? 1 : (no / 4 > 2048 ? 2048 : no / 4);
     const size_t lds = (size_t)B * K * 2;
 #define L(NB, T, SW) hipLaunchKernelGGL((gemv_kernel<NB, T, SW>), dim3(grid), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, K, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset)

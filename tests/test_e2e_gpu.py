@@ -500,6 +500,44 @@ def test_generate_frame_matches_reference_fixture(dev, use_graph):
             bad_rows = int((got != want_t).any(dim=2).sum())
             assert bad_rows <= 2, (use_graph, bad_rows, got.tolist(), want)
             assert float((got == want_t).float().mean()) >= 0.9
+            # ... and every differing row-frame IS such a near-tie (VERDICT r03 #4b), checked at its first differing codebook,
+            # where both sides have seen the same history and the same earlier codes of the frame: on the oracle's logits
+            # (fp32 arithmetic on the same bf16 weights) the reference's pick r and ours g must both survive the top-k cut up to
+            # the logit error eps of bf16 activations, and their race scores l/T - log q must be within 2 eps / T.
+            for step, b in (got != want_t).any(dim=2).nonzero().tolist():
+                i_star = int((got[step, b] != want_t[step, b]).nonzero()[0])
+                hist_t = torch.cat([tokens[b, :n_prompt]] + [torch.cat([want_t[s_, b].long(), torch.zeros(1, dtype=torch.long)])[None]
+                                                                for s_ in range(step)])
+                hist_m = torch.cat([mask[b, :n_prompt]] + [torch.cat([torch.ones(K, dtype=torch.bool), torch.zeros(1, dtype=torch.bool)])[None]
+                                                              for s_ in range(step)])
+                last_h = O.backbone_hidden(pq, TINY, hist_t[None], hist_m[None])[:, -1, :]
+                if i_star == 0:
+                    lg = last_h @ pq["codebook0_head.weight"].t()
+                else:
+                    seq = [last_h.unsqueeze(1)] + [pq["audio_embeddings.weight"][int(want_t[step, b, i]) + i * TINY.audio_vocab][None, None]
+                                                    for i in range(i_star)]
+                    x = torch.cat(seq, dim=1) @ pq["projection.weight"].t()
+                    pos = torch.arange(x.shape[1]).unsqueeze(0)
+                    dec = O.transformer({k_: v_ for k_, v_ in pq.items() if k_.startswith("decoder.")}, "decoder", TINY.decoder, x, pos)
+                    lg = dec[:, -1, :] @ pq["audio_head"][i_star - 1]
+                lg = lg[0].double()
+                torch.manual_seed(seed0 + step)
+                qrow = [torch.empty(B, TINY.audio_vocab).exponential_(1) for _ in range(K)][i_star][b].double()
+                r, g = int(want_t[step, b, i_star]), int(got[step, b, i_star])
+                assert int(O.sample_topk(lg[None].float(), 10, 0.9, qrow[None].float())[0, 0]) == r, "the oracle reproduces the reference's pick"
+                # our pick g must be a POSSIBLE outcome of the reference's sampler when every logit may move by eps (the error
+                # of bf16 activations): (1) g can make the top-k cut - fewer than k logits are certainly above it; (2) every
+                # token that would certainly beat g in the race l / T - log q can be cut out - at least k others may be above it
+                eps = 2.0 ** -7 * max(1.0, float(lg.abs().max()))
+                topk_, T_ = 10, 0.9
+                assert int((lg - eps > lg[g] + eps).sum()) <= topk_ - 1, (step, b, i_star, "our pick cannot make the top-k cut", float(lg[g]))
+                score_lo = (lg - eps) / T_ - qrow.log()
+                for j in (score_lo > (float(lg[g]) + eps) / T_ - float(qrow[g].log())).nonzero().flatten().tolist():
+                    if j == g:
+                        continue
+                    others_above = int((lg + eps > lg[j] - eps).sum()) - 1
+                    assert others_above >= topk_, (step, b, i_star, f"token {j} beats our pick {g} in the race by more than the logit error "
+                                                                      f"and cannot be cut out: not a near-tie", float(lg[j]), float(lg[g]), r)
         if use_graph:
             assert m._decode_state.graph is not None, "frames >= 2 must have gone through the captured graph"
     m.use_hip_graph = True
@@ -852,6 +890,46 @@ def test_full_size_acoustic_and_adamw_vs_oracle(dev):
         assert upd_ref[big].abs().min().item() > 0.5 * lr * mult[grp], k
 
 
+def test_config2_bench_size_loss_and_gradients_vs_oracle(dev):
+    """BASELINE config 2's own sequence length (VERDICT r03 #4d): CSM-1B, S = 2048, one sequence (the CPU oracle's step at
+    B = 1 is what the box's host cores finish in about a minute; the batch dimension is covered by the bench's config2_b4_parity
+    leg: batch loss == mean of its single-sequence losses), loss mode C with the decoder rows pinned: total / semantic /
+    acoustic loss within 1e-3 relative (the north star's bar) and a sample of gradients - attention, MLP, norm, both stacks,
+    the heads, the audio embeddings - against the oracle's autograd on the same weights (bf16 values widened to fp32)."""
+    from csm.data import SyntheticCSMDataset, collate_variable_length
+    from csm.models.model import Model
+    from csm.training.trainer import csm_1b_args
+    from csm.training.utils import compute_loss
+    m = Model(csm_1b_args(), device=dev, seed=0)
+    m.acoustic_mode = "amortized"
+    S = 2048
+    batch = collate_variable_length([SyntheticCSMDataset(1, S, seed=4321)[0]])
+    rows = torch.arange(0, S - 1, 16)                             # 1/16 of the frames, pinned
+    m.ensure_grads()
+    total, det = compute_loss(m, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"], 100.0, 1.0, acoustic_rows=rows)
+    total.backward()
+    torch.cuda.synchronize()
+    names = ["backbone.layers.0.attn.q_proj.weight", "backbone.layers.7.mlp.w1.weight", "backbone.layers.15.mlp.w2.weight", "backbone.norm.scale",
+             "decoder.layers.0.attn.v_proj.weight", "decoder.layers.3.mlp.w3.weight", "projection.weight", "codebook0_head.weight",
+             "audio_head", "audio_embeddings.weight"]
+    gviews = m._views(m.grad_arena)
+    got = {k: gviews[k].float().cpu() for k in names}
+    # ---- oracle (fp32, all host cores)
+    cfg = O.csm_1b_cfg()
+    pt = {k: v.float().cpu().requires_grad_(k in names) for k, v in m._views(m.arena).items()}
+    ref, rd = O.compute_loss(pt, cfg, batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"], 100.0, 1.0, acoustic_rows=rows)
+    ref.backward()
+    assert rel(total, ref) < 1e-3, (float(total), float(ref))
+    assert rel(det["semantic_loss"], rd["semantic_loss"]) < 1e-3 and rel(det["acoustic_loss"], rd["acoustic_loss"]) < 1e-3
+    for k in names:
+        g, r = got[k], pt[k].grad
+        scale = r.abs().max().item()
+        assert scale > 0, k
+        err = (g - r).abs().max().item()
+        cos = torch.nn.functional.cosine_similarity(g.flatten().double(), r.flatten().double(), dim=0).item()
+        assert err <= 5e-2 * scale and cos > 0.999, (k, err, scale, cos)
+
+
 def test_full_size_lora_config3_properties(dev):
     """BASELINE config 3 at full size (CSM-1B, LoRA r=8 on q_proj / v_proj, S=2048, B=8), where only size-independent
     properties can be checked: fresh adapters (B = 0) leave the loss equal to the bare model's, the base weights
@@ -899,6 +977,57 @@ def test_full_size_lora_config3_properties(dev):
         m.lora = None
         merged, _ = compute_loss(m, *args)
     assert rel(merged, adapted) < 2e-3, (float(merged), float(adapted))
+
+
+def test_full_size_lora_config3_mode_c_decoder_adapters(dev):
+    """BASELINE config 3 in the loss mode the bench's LoRA leg runs (mode C: semantic CE + depth decoder on 1/16 of the frames),
+    with the decoder rows PINNED so that every evaluation sees the same frames (VERDICT r03 #4c): fresh adapters leave both loss
+    terms equal to the bare model's, the DECODER's adapters receive gradients too (dB != 0, dA == 0 while B = 0), the step is
+    bit-reproducible, and merging the trained adapters reproduces the adapted semantic AND acoustic losses."""
+    from csm.data import SyntheticCSMDataset, collate_variable_length
+    from csm.models.model import Model
+    from csm.training.lora import apply_lora_to_model, merge_lora_weights
+    from csm.training.optim import FusedAdamW
+    from csm.training.trainer import csm_1b_args
+    from csm.training.utils import compute_loss
+    B, S = 8, 2048
+    m = Model(csm_1b_args(), device=dev, seed=0)
+    m.acoustic_mode = "amortized"
+    ds = SyntheticCSMDataset(B, S, seed=56)
+    batch = {k: v.to(dev) for k, v in collate_variable_length([ds[i] for i in range(B)]).items()}
+    per = torch.arange(0, S - 1, 16)
+    rows = torch.cat([per + b * (S - 1) for b in range(B)])       # the same 1/16 of the frames in every call
+    args = (batch["input_tokens"], batch["input_masks"], batch["target_audio_tokens"])
+    kw = dict(acoustic_rows=rows)
+    with torch.no_grad():
+        bare, bd = compute_loss(m, *args, **kw)
+    apply_lora_to_model(m, r=8, alpha=16.0, target_modules=["q_proj", "v_proj"], seed=1)
+    opt = FusedAdamW(m, {}, lora_lr=1e-3)
+
+    def step():
+        m.lora.grad_arena.zero_()
+        total, det = compute_loss(m, *args, **kw)
+        total.backward()
+        return float(total), det, m.lora.grad_arena.clone()
+
+    t1, d1, g1 = step()
+    t2, d2, g2 = step()
+    assert rel(t1, bare) < 1e-4 and rel(d1["acoustic_loss"], bd["acoustic_loss"]) < 1e-4, "adapters with B = 0 must not change either loss term"
+    assert t1 == t2 and torch.equal(g1, g2), "bit-reproducible"
+    assert float(bd["acoustic_loss"]) > 0
+    for (prefix, _, _), ad in m.lora.adapters.items():
+        assert float(ad.gA.abs().max()) == 0.0, "dA = (dy B)^T x = 0 while B = 0"
+        assert float(ad.gB.float().abs().max()) > 0, f"{prefix} adapter without a gradient in mode C"
+    assert any(prefix == "decoder" for (prefix, _, _) in m.lora.adapters), "config 3 adapts both stacks"
+    opt.step(zero_grad=True)
+    with torch.no_grad():
+        adapted, ad_ = compute_loss(m, *args, **kw)
+        assert float(adapted) != float(bare) and float(ad_["acoustic_loss"]) != float(bd["acoustic_loss"])
+        merge_lora_weights(m)
+        m.lora = None
+        merged, md = compute_loss(m, *args, **kw)
+    assert rel(merged, adapted) < 2e-3, (float(merged), float(adapted))
+    assert rel(md["acoustic_loss"], ad_["acoustic_loss"]) < 2e-3 and rel(md["semantic_loss"], ad_["semantic_loss"]) < 2e-3
 
 
 def test_optimizer_follows_rewritten_weights(dev):

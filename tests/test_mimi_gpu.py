@@ -4,8 +4,10 @@ moshi (the package the reference imports) is not installed and no Mimi weights c
 seeded random weights (codebooks randomised too: they are zero-initialised buffers in a fresh model).  Tolerances: the
 pre-quantiser latent and the decoded waveform are fp32 on both sides (different summation orders): 2e-4 of the max
 magnitude.  Codes are integers; a near-tie in the 2048-way nearest-codeword search can flip with the last fp32 bits and
-then changes the rest of that frame's residual chain, so the requirement is >= 97 % of frames identical in the semantic
-codebook and >= 90 % of all codes identical - plus exact equality when the GPU quantiser is fed HF's own latent.
+then changes the rest of that frame's residual chain.  So, besides the agreement rates (>= 97 % semantic, >= 90 % overall) and
+exact equality when the GPU quantiser is fed HF's own latent, EVERY first divergence of a frame's chain is checked to be a
+near-tie: the margin between the two candidates on our own residual (float64) is within what the measured latent difference
+explains.
 """
 import json
 
@@ -84,6 +86,39 @@ def test_mimi_encode_decode_vs_hf(dev):
         assert 0.0 <= gap <= 64 * 2.0 ** -23 * mag, f"frame {t}: HF chose a codeword {gap:.3e} farther (|x|^2+|y|^2 = {mag:.3e}): not a cdist near-tie"
     per_cb = (codes[0] == codes_hf[0]).float().mean(dim=1)
     print("end-to-end code agreement per codebook:", [round(float(v), 3) for v in per_cb])
+    # ---- EVERY end-to-end disagreement is a near-tie (VERDICT r03 #4a): no statistical threshold on integer output.
+    # Walk both residual chains (1 semantic codebook, 31 acoustic ones) in float64.  At the FIRST codebook of a chain where the
+    # two sides differ on a frame, both have subtracted the same codewords so far, so the two residuals differ only by the
+    # projected latent error delta = x_hf - x_ours (measured here, frame by frame, not assumed).  Ours picked a = the exact
+    # nearest codeword of ITS residual (checked), HF picked b = the nearest of its own up to the cancellation noise of its fp32
+    # cdist; then the margin on our residual is bounded:  0 <= d(x_ours, b) - d(x_ours, a) <= 2 |delta| |a - b| + cdist noise.
+    # Past the first divergence a frame's later codes quantise different residuals and are not comparable: not checked.
+    lat64, lat_hf64 = lat.double(), lat_hf.double()
+    n_ties, n_checked = 0, 0
+    for name, lo, q in (("semantic", 0, "quantizer.semantic_residual_vector_quantizer"),
+                        ("acoustic", 1, "quantizer.acoustic_residual_vector_quantizer")):
+        Win = codec.w[f"{q}.in"].cpu().double()                       # [256, 512]
+        books = codec.cb[name].cpu().double()                         # [n, 2048, 256]
+        x_o, x_h = lat64 @ Win.t(), lat_hf64 @ Win.t()                # [T, 256] residuals of the two sides
+        alive = torch.ones(x_o.shape[0], dtype=torch.bool)            # frames whose chains still agree
+        for k in range(books.shape[0]):
+            co, ch = codes[0, lo + k], codes_hf[0, lo + k]
+            d_o = ((x_o[:, None, :] - books[k][None, :, :]) ** 2).sum(-1)            # [T, 2048] exact distances on OUR residual
+            assert torch.equal(co[alive], d_o.argmin(-1)[alive]), f"{name} codebook {k}: our code is not the exact nearest codeword of our own residual"
+            for t in (alive & (co != ch)).nonzero().flatten().tolist():
+                a_, b_ = books[k][co[t]], books[k][ch[t]]
+                gap = float(d_o[t, ch[t]] - d_o[t, co[t]])
+                delta = float((x_h[t] - x_o[t]).norm())
+                noise = 64 * 2.0 ** -23 * float((x_h[t] ** 2).sum() + (b_ ** 2).sum())
+                bound = 2.0 * delta * float((a_ - b_).norm()) + noise
+                assert 0.0 <= gap <= bound, (f"{name} codebook {k}, frame {t}: HF's codeword is {gap:.3e} farther on our residual, but the latent "
+                                             f"difference |delta| = {delta:.3e} only explains {bound:.3e}: not a near-tie")
+                n_ties += 1
+            n_checked += int(alive.sum())
+            alive &= co == ch
+            x_o = x_o - books[k][co]
+            x_h = x_h - books[k][ch]
+    print(f"{n_ties} first divergences over {n_checked} (frame, codebook) searches on agreeing chains: every one a near-tie within the measured latent difference")
     # decoder on HF's codes
     out = codec.decode(codes_hf).cpu()
     assert out.shape == wav_hf.shape, (out.shape, wav_hf.shape)
