@@ -181,7 +181,11 @@ class FusedAdamW:
         ``skip``: a device int32 tensor; non-zero means "drop this step" (weights and moments untouched, gradients cleared
         as ``zero_grad`` says).  The decision stays on the device - it travels to the kernels as a negative clip coefficient -
         so the host launches the same work either way (training/dp.py: text-row exchange over capacity).  The caller
-        un-counts a dropped step with ``uncount_step`` once the host has seen the flag."""
+        un-counts a dropped step with ``uncount_step`` once the host has seen the flag.  (Known deviation, ADVICE r03: the host
+        sees the flag of step k at ``arm()`` of step k + 2, so step k + 1 runs its bias correction with t one too high - a
+        factor (1 - beta^t) / (1 - beta^(t+1)) on one step.  Steps are only ever dropped while the text-row exchange capacity
+        grows, i.e. in the first steps of a run; the counter stays on the host so that the kernels' bias corrections remain the
+        host-computed doubles torch's AdamW uses.)"""
         self._settle()
         self.step_count += 1
         self.model._fp32_source = None          # the weights move on: the loaded fp32 dict no longer describes them

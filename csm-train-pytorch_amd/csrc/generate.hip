@@ -553,6 +553,16 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
     float* pw = kn + (size_t)NB * KV * HD;                                  // [waves][64] probabilities
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rep = H / KV;
+    // the wave's first weight row: requested before the attention prologue (it depends on nothing here; round 4: behind the two
+    // barriers below its latency was the tail of every one of the 128 launches per frame)
+    constexpr int KCH = 2;                                                  // K = H * HD = 1024 in the depth decoder: 2 chunks per lane
+    const int row0 = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    const bool pre = (K == 512 * KCH) && row0 < N;
+    U4 wq0[KCH] = {};
+    if (pre) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) wq0[c] = *reinterpret_cast<const U4*>(W + (size_t)row0 * ldw + lane * 8 + 512 * c);
+    }
     // ---- RoPE of q (all heads) and of the new k (all kv heads); workgroup 0 appends k, v to the caches
     for (int it = threadIdx.x; it < NB * (H + KV) * (HD / 2); it += blockDim.x) {
         const int i = it % (HD / 2), hh = (it / (HD / 2)) % (H + KV), b = it / ((HD / 2) * (H + KV));
@@ -638,15 +648,31 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = 0.f;
         const bf16_t* w = W + (size_t)nrow * ldw;
-        for (int k = lane * 8; k < K; k += 512) {
-            float wf[8];
-            unpack8(*reinterpret_cast<const U4*>(w + k), wf);
+        if (pre && nrow == row0) {                       // (wave-uniform) the prefetched row: the same chunks in the same order
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float xf[8];
-                unpack8(*reinterpret_cast<const U4*>(xs + b * K + k), xf);
+            for (int c = 0; c < KCH; ++c) {
+                const int k = lane * 8 + 512 * c;
+                float wf[8];
+                unpack8(wq0[c], wf);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[b] += wf[j] * xf[j];
+                for (int b = 0; b < NB; ++b) {
+                    float xf[8];
+                    unpack8(*reinterpret_cast<const U4*>(xs + b * K + k), xf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[b] += wf[j] * xf[j];
+                }
+            }
+        } else {
+            for (int k = lane * 8; k < K; k += 512) {
+                float wf[8];
+                unpack8(*reinterpret_cast<const U4*>(w + k), wf);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float xf[8];
+                    unpack8(*reinterpret_cast<const U4*>(xs + b * K + k), xf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[b] += wf[j] * xf[j];
+                }
             }
         }
 #pragma unroll

@@ -108,6 +108,15 @@ def test_library_exports_every_declared_symbol():
     assert hip.lib.csm_abi_version() == 3
 
 
+def test_only_one_library_in_the_tree():
+    """What ships to the GPU box is the tree: a second shared library in it (an A/B build under tools/probes/build/, a stale copy)
+    is one CSM_HIP_LIB typo away from being the library under test.  The probe scripts build theirs into
+    tools/probes/build/abl/ and they are deleted before a round ends."""
+    import glob
+    libs = [p for p in glob.glob(os.path.join(ROOT, "**", "*.so"), recursive=True) if "/.git/" not in p and "/gpurun_out/" not in p]
+    assert [os.path.relpath(p, ROOT) for p in libs] == ["csm-train-pytorch_amd/csm/hip/libcsm_hip.so"], libs
+
+
 def test_product_path_has_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
