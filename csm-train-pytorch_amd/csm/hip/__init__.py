@@ -111,6 +111,8 @@ if os.environ.get("CSM_GEMM_W4") == "0":                # kernel A/B only (tools
     lib.csm_set_gemm_tuning(1, 0)
 if os.environ.get("CSM_GEMM_FAST_EPI") == "0":          # kernel A/B only (tools/probes)
     lib.csm_set_gemm_tuning(6, 0)
+if os.environ.get("CSM_GEMM_W4_N6") == "0":             # kernel A/B only: 256 x 192 tiles off
+    lib.csm_set_gemm_tuning(8, 0)
 if os.environ.get("CSM_GEMM_W4_KEXT") == "0":           # kernel A/B only: K-extension (LoRA) products on the eight-wave kernel
     lib.csm_set_gemm_tuning(7, 0)
 if os.environ.get("CSM_GEMM_STAGGER"):                  # "groups,fwd,bwd,other" (10 ns ticks): kernel A/B only (tools/probes)

@@ -265,13 +265,14 @@ extern "C" const char* csm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 // key 1 = the auto variant gives batch-1 products without K-extension to the four-wave kernel (default 1)
 extern int g_gemm_touch;
 extern int g_w4_stagger[4];
-extern int g_w4_fast_epi;
+extern int g_w4_fast_epi, g_w4_n6;
 extern "C" int csm_set_gemm_tuning(int key, int value) {
-    CSM_REQUIRE(key >= 0 && key <= 7, "csm_set_gemm_tuning: unknown key %d", key);
+    CSM_REQUIRE(key >= 0 && key <= 8, "csm_set_gemm_tuning: unknown key %d", key);
     if (key == 0) g_gemm_touch = value ? 1 : 0;
     else if (key == 1) g_gemm_w4 = value ? 1 : 0;
     else if (key == 6) g_w4_fast_epi = value ? 1 : 0;
     else if (key == 7) g_w4_kext = value ? 1 : 0;
+    else if (key == 8) g_w4_n6 = value ? 1 : 0;
     else {      // 2: number of start groups of a persistent four-wave launch; 3 / 4 / 5: offset between groups in 10 ns ticks
         CSM_REQUIRE(value >= 0 && value <= (key == 2 ? 32 : 20000), "csm_set_gemm_tuning: key %d value %d out of range", key, value);
         g_w4_stagger[key - 2] = key == 2 ? (value < 1 ? 1 : value) : value;

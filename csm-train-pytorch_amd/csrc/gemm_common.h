@@ -243,6 +243,16 @@ struct Epi {
 // Llama3ScaledRoPE applied to the fp32 accumulator, one bf16 rounding instead of the stand-alone kernel's two.
 enum { EPI_NONE = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2, EPI_ROPE = 3 };
 
+// one pair through its (cos, sin): x0' = fma(x0, c, -(x1 s)), x1' = fma(x1, c, x0 s), the products x1 s / x0 s rounded first - written out
+// so that every inlined copy of an epilogue rounds the same way (left to the compiler, two copies of the same expression were contracted
+// differently: one-ulp differences at bf16 ties between the 256 x 256 and the 256 x 192 tile kernels, round 4)
+__device__ __forceinline__ void rope_rot(float& x0, float& x1, float c, float s) {
+#pragma clang fp contract(off)
+    const float p = x1 * s, q = x0 * s;
+    const float a0 = __builtin_fmaf(x0, c, -p), a1 = __builtin_fmaf(x1, c, q);
+    x0 = a0; x1 = a1;
+}
+
 // rotate NP adjacent pairs v[0..2NP) that start at column n of row m (n even, all pairs inside one head)
 template <int NP>
 __device__ __forceinline__ void epi_rope(const Epi& e, int m, int n, float* v) {
@@ -253,9 +263,8 @@ __device__ __forceinline__ void epi_rope(const Epi& e, int m, int n, float* v) {
 #pragma unroll
     for (int i = 0; i < NP; i += 2) {
         const float4 cs = *reinterpret_cast<const float4*>(t + 2 * i);      // c_i, s_i, c_{i+1}, s_{i+1}
-        const float a0 = v[2 * i] * cs.x - v[2 * i + 1] * cs.y, a1 = v[2 * i + 1] * cs.x + v[2 * i] * cs.y;
-        const float a2 = v[2 * i + 2] * cs.z - v[2 * i + 3] * cs.w, a3 = v[2 * i + 3] * cs.z + v[2 * i + 2] * cs.w;
-        v[2 * i] = a0; v[2 * i + 1] = a1; v[2 * i + 2] = a2; v[2 * i + 3] = a3;
+        rope_rot(v[2 * i], v[2 * i + 1], cs.x, cs.y);
+        rope_rot(v[2 * i + 2], v[2 * i + 3], cs.z, cs.w);
     }
 }
 
@@ -411,20 +420,22 @@ __device__ __forceinline__ void epi_store_pair(const Epi& e, bool vec_ok, int m,
 // be merged or dropped, whereas the loads here are the compiler's (it may fuse or elide them), and a count that is too high
 // would let an LDS read overtake its LDS-DMA.  Too low only waits longer - and the loads precede the stores
 // that depend on them, so nothing is lost.
-template <typename OutT, int NI>
+// NJP = pairs of horizontally adjacent 16 x 16 accumulators per row of the block (2: 64 columns; 1: the 32-column remainder of
+// a 96-column wave block of the 256 x 192 tile).
+template <typename OutT, int NI, int NJP = 2>
 __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int nb, int lane, const f32x4 (&acc)[NI][4]) {
     bool fast = false;
     if constexpr (sizeof(OutT) == 2)
         fast = vec_ok && (e.mode == EPI_NONE || (e.mode == EPI_ROPE && (e.p0 & 63) == 0 && (e.p1 & 7) == 0) ||
                           (e.mode == EPI_SWIGLU_FWD && (e.ld_aux & 3) == 0)) &&
-               (e.ldc & 7) == 0 && (!e.R || (e.ldr & 7) == 0) && nb + 63 < e.N && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) &&
+               (e.ldc & 7) == 0 && (!e.R || (e.ldr & 7) == 0) && nb + 32 * NJP - 1 < e.N && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0) &&
                (!e.R || (reinterpret_cast<uintptr_t>(e.R) & 15) == 0);
     if (!fast) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int m = mb + 16 * i + (lane & 15);
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) epi_store_pair<OutT>(e, vec_ok, m, nb + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
+            for (int jp = 0; jp < NJP; ++jp) epi_store_pair<OutT>(e, vec_ok, m, nb + 32 * jp, lane, acc[i][2 * jp], acc[i][2 * jp + 1]);
         }
         return 0;
     }
@@ -450,7 +461,7 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) {
+                    for (int jp = 0; jp < NJP; ++jp) {
                         const int pos = (ml + 16 * (i + ii)) % e.ld_aux, n = nl + 32 * jp;
                         const float* t = table + ((size_t)pos * (e.p1 >> 1) + ((n % e.p1) >> 1)) * 2;
                         dst[ii][jp][0] = *reinterpret_cast<const float4*>(t);
@@ -463,7 +474,7 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                 if ((i & 1) == 0 && i + 2 < NI) rope_fetch(i + 2, cs[((i >> 1) + 1) & 1]);
                 const int m = ml + 16 * i;
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
+                for (int jp = 0; jp < NJP; ++jp) {
                     float v[8];
                     gather(i, jp, v);
                     const int n = nl + 32 * jp;
@@ -474,16 +485,18 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                         for (int k = 0; k < 8; ++k) v[k] += f[k];
                     }
                     const float4 (&q)[2] = cs[(i >> 1) & 1][i & 1][jp];
+                    // (a block of the 256 x 192 tile starts at a multiple of 32: the rotated region may end between its two
+                    //  32-column halves - never inside one, p0 being a multiple of 64; uniform per half)
+                    if (nb + 32 * jp < e.p0)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {                       // pairs (4h, 4h+1) and (4h+2, 4h+3)
-                        const float a0 = v[4 * h] * q[h].x - v[4 * h + 1] * q[h].y, a1 = v[4 * h + 1] * q[h].x + v[4 * h] * q[h].y;
-                        const float a2 = v[4 * h + 2] * q[h].z - v[4 * h + 3] * q[h].w, a3 = v[4 * h + 3] * q[h].z + v[4 * h + 2] * q[h].w;
-                        v[4 * h] = a0; v[4 * h + 1] = a1; v[4 * h + 2] = a2; v[4 * h + 3] = a3;
+                        rope_rot(v[4 * h], v[4 * h + 1], q[h].x, q[h].y);
+                        rope_rot(v[4 * h + 2], v[4 * h + 3], q[h].z, q[h].w);
                     }
                     if (m < e.M) store16_asm(C + (size_t)m * e.ldc + n, pack8(v));
                 }
             }
-            return 2 * NI;        // the 2 NI asm stores (the 4 NI table loads are the compiler's: not counted)
+            return NJP * NI;      // the asm stores (the table loads are the compiler's: not counted)
         }
         // ---- everything else: all residual rows of the block first
         U4 rr[NI][2];
@@ -491,14 +504,14 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp)      // rows past M read row M-1 (never stored): no branch between the loads
+                for (int jp = 0; jp < NJP; ++jp)    // rows past M read row M-1 (never stored): no branch between the loads
                     rr[i][jp] = *reinterpret_cast<const U4*>(e.R + (size_t)min(ml + 16 * i, e.M - 1) * e.ldr + nl + 32 * jp);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int m = ml + 16 * i;
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
+            for (int jp = 0; jp < NJP; ++jp) {
                 float v[8];
                 gather(i, jp, v);
                 if (e.R) {
@@ -520,7 +533,7 @@ __device__ __forceinline__ int epi_block(const Epi& e, bool vec_ok, int mb, int 
                 }
             }
         }
-        return 2 * NI * (1 + (e.mode == EPI_SWIGLU_FWD ? 1 : 0));      // asm stores only
+        return NJP * NI * (1 + (e.mode == EPI_SWIGLU_FWD ? 1 : 0));    // asm stores only
     }
     return 0;
 }

@@ -101,7 +101,8 @@ int csm_set_gemm256_persistent(int v);
 int csm_get_gemm256_persistent(void);
 /* tuning switches for A/B runs: key 0 = the eight-wave 256x256 kernel touches the tile of a fused epilogue's read operand
  * (gate/up of the SwiGLU backward, a bf16 residual) during its K loop so that the epilogue's loads hit cache (default 1);
- * key 1 = the auto variant hands batch-1 products without K-extension to the four-wave kernel (default 1) */
+ * key 1 = the auto variant hands batch-1 products without K-extension to the four-wave kernel (default 1);
+ * key 8 (round 4) = the four-wave kernel uses 256 x 192 output tiles where they fill the rounds of the 256 CUs better (default 1) */
 int csm_set_gemm_tuning(int key, int value);
 /* name of the kernel (rocprofv3 spelling, without the argument list) the most recent csm_gemm_* call on this host thread's
  * library instance launched - for benchmarks that attribute time to kernels; not thread-safe */

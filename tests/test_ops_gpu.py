@@ -962,6 +962,60 @@ def test_gemm_four_wave_kernel_fused_epilogues(dev):
             assert torch.equal(a, b), key
 
 
+def test_gemm_four_wave_256x192_tiles_equal_256x256(dev):
+    """Round 4: where 256 x 192 output tiles fill the rounds of the 256 CUs better than 256 x 256 ones (the fused q|k|v projection of
+    the bench batch: 384 tiles = 1.5 rounds become 512 tiles of 3/4 the work = 2 rounds of 3/4), the four-wave kernel takes them
+    (gemm256w4n6_kernel; csm_set_gemm_tuning(8, 0) switches it off).  Each output element is the same k-ordered sum through the
+    same MFMA, so the results are bit-equal: plain, with a residual that aliases the output, with the RoPE epilogue whose
+    rotated/unrotated boundary falls inside a 192-column tile, with A transposed, one round and several rounds."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(1906)
+    hd = 64
+    cases = [(256, 768, 64, False, None), (256, 768, 192, True, None), (512, 1536, 1024, False, (128, 1280)),
+             (8192, 1536, 2048, False, None), (8192, 3072, 2048, False, (2048, 2560)), (16384, 1536, 1024, False, (2048, 1280)),
+             (2048, 3072, 320, True, None)]
+    for (M, N, K, tA, rope) in cases:
+        A = rnd((K, M) if tA else (M, K), g).to(dev)
+        B = rnd((N, K), g, 0.1).to(dev)
+        R = rnd((M, N), g).to(dev)
+        out = {}
+        try:
+            for on in (1, 0):
+                ops.lib.csm_set_gemm_tuning(8, on)
+                ops.lib.csm_set_gemm_variant(4)
+                C = torch.empty(M, N, dtype=BF, device=dev)
+                ops.gemm(A, B, C, None, tA, False)
+                name = ops.lib.csm_gemm_last_kernel().decode()
+                assert name.startswith("gemm256w4n6_kernel" if on else "gemm256w4_kernel"), (name, M, N, K)
+                acc = R.clone()
+                ops.gemm(A, B, acc, acc, tA, False, alpha=0.5)
+                res = [C, acc]
+                if rope is not None and not tA:
+                    S, p0 = rope
+                    table = O.rope_table(S, hd).to(dev).contiguous()
+                    qkv = torch.empty(M, N, dtype=BF, device=dev)
+                    ops.linear_rope_fwd(A, B, qkv, table, S, p0, hd)
+                    assert ops.lib.csm_gemm_last_kernel().decode().startswith("gemm256w4n6_kernel" if on else "gemm256w4_kernel")
+                    res.append(qkv)
+                out[on] = res
+        finally:
+            ops.lib.csm_set_gemm_variant(2)
+            ops.lib.csm_set_gemm_tuning(8, 1)
+        for i, (a, b) in enumerate(zip(out[0], out[1])):
+            assert torch.equal(a, b), f"{M}x{N}x{K} tA={tA} output {i}: {(a.float() - b.float()).abs().max().item()}"
+        ref = (A.float().t() if tA else A.float()) @ B.float().t()
+        close(f"w4n6 {M}x{N}x{K}", out[1][0], ref, 1e-2)
+    # shapes the 192-column tiling does not help (or cannot take) keep the 256 x 256 kernel
+    for (M, N, K) in [(4096, 2048, 512), (16384, 3072, 128), (300, 768, 64)]:
+        A, B = rnd((M, K), g).to(dev), rnd((N, K), g).to(dev)
+        ops.lib.csm_set_gemm_variant(4)
+        try:
+            ops.gemm(A, B, torch.empty(M, N, dtype=BF, device=dev), None, False, False)
+            assert ops.lib.csm_gemm_last_kernel().decode().startswith("gemm256w4_kernel"), (M, N, K)
+        finally:
+            ops.lib.csm_set_gemm_variant(2)
+
+
 @pytest.mark.parametrize("B,S,H,KV", [(1, 64, 4, 1), (1, 128, 4, 1), (2, 192, 8, 2), (1, 512, 8, 2), (2, 320, 4, 1), (3, 384, 4, 1), (1, 2048, 8, 2)])
 def test_attention_backward_generated_asm_kernels(dev, B, S, H, KV):
     """attention64_asm.hip (round 4): the dK/dV pass as one wave per (64 keys, query head) and the dQ pass as one wave per (64

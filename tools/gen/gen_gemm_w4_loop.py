@@ -31,13 +31,17 @@ VATC = 222                                  # v[222:229] the same + current stag
 S_RA, S_RB = 40, 44                         # buffer resource descriptors (4 SGPRs each)
 S_STA, S_STB = 48, 50                       # steps (64-bit)
 S_T, S_NT, S_SLA, S_SLB, S_TMP, S_WOFF, S_B3, S_T2 = 52, 53, 54, 55, 56, 57, 58, 59
+S_WOFFB = 68                                # this wave's LDS offset inside a B half-tile (= S_WOFF for 4 pieces per wave; wave * 3072 for 3)
 S_LA, S_LB = 60, 61                         # LDS byte offsets of the CURRENT tile's A / B stage (for the reads)
 
 
-def frag_reads(T, dst, cur0, cur1, curt, ks):
-    """LDS reads of 8 tiles' fragments for k-step ks into registers dst + 4 * tile."""
+NJ = 8          # n-tiles (16 columns each) of a wave's block: 8 (256-column tiles) or 6 (192-column tiles, K-contiguous B only)
+
+
+def frag_reads(T, dst, cur0, cur1, curt, ks, n=8):
+    """LDS reads of n tiles' fragments for k-step ks into registers dst + 4 * tile."""
     out = []
-    for i in range(8):
+    for i in range(n):
         r = dst + 4 * i
         if T == 0:
             out.append(f"ds_read_b128 v[{r}:{r + 3}], v{cur1 if ks else cur0} offset:{i * 2048}")
@@ -48,11 +52,12 @@ def frag_reads(T, dst, cur0, cur1, curt, ks):
 
 
 def dma_half(which, h, op_base):
-    """my 4 pieces of half-tile h of operand `which` ('A' | 'B') for the tile the resource descriptor points at"""
+    """my pieces of half-tile h of operand `which` ('A' | 'B') for the tile the resource descriptor points at: 4 of the 16 of a
+    128-row half; 3 of the 12 of a 96-row B half (NJ = 6: the wave's LDS offset inside the half is then wave * 3072, s[S_WOFFB])"""
     out = []
     rs = S_RA if which == "A" else S_RB
     sl = S_SLA if which == "A" else S_SLB
-    for i in range(4):
+    for i in range(4 if which == "A" else NJ // 2):
         out.append(f"s_add_u32 m0, s{sl}, {h * 16384 + i * 1024}")
         out.append("s_nop 0")
         out.append(f"buffer_load_dwordx4 %{op_base + 4 * h + i}, s[{rs}:{rs + 3}], 0 offen lds")
@@ -63,7 +68,7 @@ def mfmas(sa, sb, zero=False):
     """64 MFMAs of one k-step; ``zero``: the accumulators START here (C = 0: the first k-step of an output tile)"""
     out = []
     for i in range(8):
-        for j in range(8):
+        for j in range(NJ):
             c = (i * 8 + j) * 4
             src_c = "0" if zero else f"a[{c}:{c + 3}]"
             out.append(f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], v[{sb + 4 * j}:{sb + 4 * j + 3}], v[{sa + 4 * i}:{sa + 4 * i + 3}], {src_c}")
@@ -153,6 +158,11 @@ def descriptors(opA, opB, opStA, opStB, opNt, opWoff):
     e(f"s_and_b32 s{S_RA + 1}, s{S_RA + 1}, 0xffff"); e(f"s_and_b32 s{S_RB + 1}, s{S_RB + 1}, 0xffff")
     e(f"s_mov_b64 s[{S_STA}:{S_STA + 1}], %{opStA}"); e(f"s_mov_b64 s[{S_STB}:{S_STB + 1}], %{opStB}")
     e(f"s_mov_b32 s{S_NT}, %{opNt}"); e(f"s_mov_b32 s{S_WOFF}, %{opWoff}")
+    if NJ == 8:
+        e(f"s_mov_b32 s{S_WOFFB}, s{S_WOFF}")
+    else:       # operand = sbase + wave * 4096 (4 pieces of 1 KiB per wave and half); with 3 pieces: sbase + wave * 3072
+        e(f"s_and_b32 s{S_TMP}, s{S_WOFF}, 0x3fff"); e(f"s_lshr_b32 s{S_TMP}, s{S_TMP}, 2")      # wave * 1024  (sbase is a multiple of 16 KiB)
+        e(f"s_sub_u32 s{S_WOFFB}, s{S_WOFF}, s{S_TMP}")
     return L
 
 
@@ -161,11 +171,11 @@ def gen_pro():
     lane offsets [A0 x4, A1 x4, B0 x4, B1 x4], %16 A base, %17 B base, %18 A step, %19 B step, %20 nt, %21 wave LDS offset."""
     L = descriptors(16, 17, 18, 19, 20, 21)
     e = L.append
-    e(f"s_mov_b32 s{S_SLA}, s{S_WOFF}"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x10000")
+    e(f"s_mov_b32 s{S_SLA}, s{S_WOFF}"); e(f"s_add_u32 s{S_SLB}, s{S_WOFFB}, 0x10000")
     L += dma_half("A", 0, 0) + dma_half("A", 1, 0) + dma_half("B", 0, 8) + dma_half("B", 1, 8)
     L += ADV
     L += set_records("1")
-    e(f"s_add_u32 s{S_SLA}, s{S_WOFF}, 0x8000"); e(f"s_add_u32 s{S_SLB}, s{S_WOFF}, 0x18000")
+    e(f"s_add_u32 s{S_SLA}, s{S_WOFF}, 0x8000"); e(f"s_add_u32 s{S_SLB}, s{S_WOFFB}, 0x18000")
     L += dma_half("A", 0, 0) + dma_half("A", 1, 0) + dma_half("B", 0, 8) + dma_half("B", 1, 8)
     return L
 
@@ -197,7 +207,7 @@ def gen(TA, TB):
     e("s_barrier")
     e(f"s_mov_b32 s{S_T}, 0"); e(f"s_mov_b32 s{S_B3}, 0"); e(f"s_mov_b32 s{S_LA}, 0"); e(f"s_mov_b32 s{S_LB}, 0x10000")
     L += set_cur(TA, TB)
-    L += frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
+    L += frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0, NJ)
     e("s_waitcnt lgkmcnt(0)")
     def ks0(zero):
         K0 = []
@@ -207,11 +217,11 @@ def gen(TA, TB):
         # B stage of tile t+2 = the stage tile t-1 used = (s58 + 2) % 3
         k(f"s_add_u32 s{S_TMP}, s{S_B3}, 2"); k(f"s_cmp_ge_u32 s{S_TMP}, 3"); k(f"s_cselect_b32 s{S_SLB}, {-3 & 0xffffffff}, 0")
         k(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_TMP}")
-        k(f"s_lshl_b32 s{S_SLB}, s{S_SLB}, 15"); k(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); k(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFF}")
+        k(f"s_lshl_b32 s{S_SLB}, s{S_SLB}, 15"); k(f"s_add_u32 s{S_SLB}, s{S_SLB}, 0x10000"); k(f"s_add_u32 s{S_SLB}, s{S_SLB}, s{S_WOFFB}")
         # fragments (t, ks1) -> Q within the first 44 MFMAs, the 8 B(t+2) requests spread over all 64
-        reads_q = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1)
+        reads_q = frag_reads(TA, QA, VAC0, VAC1, VATC, 1) + frag_reads(TB, QB, VBT0, VBT1, VBC, 1, NJ)
         dmaB = dma_half("B", 0, 11) + dma_half("B", 1, 11)
-        return K0 + weave(mfmas(PA, PB, zero), [(reads_q, 0, 44), (dmaB, 2, 64)])
+        return K0 + weave(mfmas(PA, PB, zero), [(reads_q, 0, 44 * NJ // 8), (dmaB, 2, 8 * NJ)])
     # ---- K-tile 0's first k-step, peeled: its MFMAs start the accumulators (C = 0); then into the loop at its mid-tile point
     L += ks0(True)
     e("s_branch 5f")
@@ -223,15 +233,15 @@ def gen(TA, TB):
     # ended with a touch (s65), that touch, which is younger than every piece this wait is for
     e("s_waitcnt lgkmcnt(0)")
     e(f"s_cmp_eq_u32 s{S_TFLAG}, 0"); e("s_cbranch_scc1 8f")
-    e("s_waitcnt vmcnt(9)"); e(f"s_mov_b32 s{S_TFLAG}, 0"); e("s_branch 9f")
-    e("8:"); e("s_waitcnt vmcnt(8)")
+    e(f"s_waitcnt vmcnt({NJ + 1})"); e(f"s_mov_b32 s{S_TFLAG}, 0"); e("s_branch 9f")
+    e("8:"); e(f"s_waitcnt vmcnt({NJ})")
     e("9:"); e("s_barrier")
     # ---- ks1: fragments of (t+1, ks0) -> P and A(t+2) into the stage tile t just left
     e(f"s_add_u32 s{S_SLA}, s{S_LA}, s{S_WOFF}")                                     # A stage of tile t (free now) for the t+2 requests
     L += next_stage_offsets()
-    reads_p = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0)
+    reads_p = set_cur(TA, TB) + frag_reads(TA, PA, VAC0, VAC1, VATC, 0) + frag_reads(TB, PB, VBT0, VBT1, VBC, 0, NJ)
     dmaA = dma_half("A", 0, 3) + dma_half("A", 1, 3) + ADV
-    L += weave(mfmas(QA, QB), [(reads_p, 0, 44), (dmaA, 2, 64)])
+    L += weave(mfmas(QA, QB), [(reads_p, 0, 44 * NJ // 8), (dmaA, 2, 8 * NJ)])
     # ---- a touch (epilogue-read prefetch) every (s63 + 1) K-tiles while any are left, AFTER this K-tile's last A request: it is
     # then younger than everything the next K-tile's wait is for and stays in flight across it (vmcnt(9) there), i.e. it has
     # two K-tiles to come back from HBM before a wait insists on it
@@ -251,6 +261,7 @@ def gen(TA, TB):
 
 
 def main(path):
+    global NJ
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen/gen_gemm_w4_loop.py - do not edit.  The K loop of gemm256w4.hip as inline-asm text,\n"
                 "// one macro per operand-layout pair (TA, TB: 0 = K-contiguous LDS image, 1 = K-strided image).\n")
@@ -270,6 +281,19 @@ def main(path):
         for ins in gen_pro():
             f.write(f'    "{ins}\\n\\t" \\\n')
         f.write('    ""\n')
+        # 256 x 192 tiles (round 4): the wave's block is 8 x 6 accumulators, the B half-tile 96 rows = 3 LDS-DMA pieces per wave;
+        # K-contiguous B only (the fused q|k|v projections: 384 tiles of 256 x 256 are 1.5 rounds of the 256 CUs, 512 of 256 x 192 two)
+        NJ = 6
+        for TA in (0, 1):
+            f.write(f"#define CSM_W4N6_LOOP_{TA}0 \\\n")
+            for ins in gen(TA, 0):
+                f.write(f'    "{ins}\\n\\t" \\\n')
+            f.write('    ""\n')
+        f.write("#define CSM_W4N6_PRO \\\n")
+        for ins in gen_pro():
+            f.write(f'    "{ins}\\n\\t" \\\n')
+        f.write('    ""\n')
+        NJ = 8
         # one 32-deep k-step whose fragments arrive as operands (K-extension: a LoRA group's columns after the main loop):
         # %0..%7 the wave's 8 A-row fragments, %8..%15 its 8 B-row fragments
         f.write("#define CSM_W4_KEXT \\\n")
@@ -280,8 +304,8 @@ def main(path):
         f.write('    "s_nop 7\\n\\ts_nop 7\\n\\t" \\\n    ""\n')
         f.write("#define CSM_W4_KEXT_CLOBBERS " + ", ".join(f'"a{n}"' for n in range(256)) + "\n")
         f.write("#define CSM_W4_CLOBBERS " + ", ".join([f'"v{n}"' for n in range(64, 234)] + [f'"a{n}"' for n in range(256)] +
-                                                      [f'"s{n}"' for n in range(40, 68)] + ['"scc"', '"vcc"', '"memory"']) + "\n")
-        f.write("#define CSM_W4_PRO_CLOBBERS " + ", ".join([f'"s{n}"' for n in range(40, 62)] + ['"scc"', '"memory"']) + "\n")
+                                                      [f'"s{n}"' for n in range(40, 70)] + ['"scc"', '"vcc"', '"memory"']) + "\n")
+        f.write("#define CSM_W4_PRO_CLOBBERS " + ", ".join([f'"s{n}"' for n in range(40, 62)] + ['"s68"', '"s69"', '"scc"', '"memory"']) + "\n")
 
 
 if __name__ == "__main__":
