@@ -40,6 +40,8 @@ GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
 DEFER_ATTN_DW = int(_os.environ.get("CSM_DEFER_ATTN_DW", "3"))
 # the RMSNorm scale gradients' column sums of a layer (and of the layers whose attention gradients are deferred) in one launch
 DEFER_NORM_DW = _os.environ.get("CSM_DEFER_NORM_DW", "1") == "1"
+# the depth decoder's fused attention + output projection takes its position as a launch argument (A/B: 0 = from device memory)
+DECODE_POS_HOST = _os.environ.get("CSM_DECODE_POS_HOST", "1") == "1"
 # LoRA groups ride on the frozen projections' GEMMs as K-extension operands (training/lora.py); 0 = per-adapter products
 LORA_FUSE = _os.environ.get("CSM_LORA_FUSE", "1") != "0"
 
@@ -800,6 +802,8 @@ class _DecodeStack:
         # more than the launch it saves from two rows on (measured: 149 vs 147 frames/s at B = 1, 331 vs 402 aggregate at B = 4)
         import os
         self.fuse_attn = B == 1 and s_max <= 64 and hd == 128 and os.environ.get("CSM_DECODE_FUSE_ATTN", "1") == "1"
+        # the position as a host integer where the caller knows it (the depth decoder: step i is at position i): see ops.gemv_attn
+        self.pos_host = None
 
     def fill_from(self, acts, B, S):
         """Copy the post-RoPE K / V rows of a prefilled prompt into the caches."""
@@ -833,7 +837,7 @@ class _DecodeStack:
             if self.fuse_attn:
                 # (depth decoder: <= 32 cached positions - the attention rides in the prologue of the output projection)
                 ops.gemv_attn(self.qkv, self.k[i], self.v[i], self.pos, table, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, cur,
-                              H, KV, hd)
+                              H, KV, hd, pos_host=self.pos_host)
             else:
                 ops.attn_decode_rope(self.qkv, self.k[i], self.v[i], self.o, self.pos, table, H, KV, hd)
                 ops.gemv(self.o, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, residual=cur)
@@ -971,4 +975,5 @@ class DecodeState:
             ops.gemv_ex(m.block("audio_embeddings.weight"), m.block("projection.weight"), self.proj, row_index=code,
                         row_offset=(i - 1) * m.args.audio_vocab_size)
         self.dc.pos = self.dpos[i]
+        self.dc.pos_host = i if DECODE_POS_HOST else None
         return self.dc.step(self.proj, final_norm=final_norm)

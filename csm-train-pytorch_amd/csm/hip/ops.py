@@ -423,12 +423,18 @@ def attn_decode_rope(qkv, kcache, vcache, out, pos_i32, table, H, KV, HD):
     return out
 
 
-def gemv_attn(qkv, kcache, vcache, pos_i32, table, W, y, residual, H, KV, HD):
+def gemv_attn(qkv, kcache, vcache, pos_i32, table, W, y, residual, H, KV, HD, pos_host=None):
     """A depth-decoder layer's rope + append + attention + output projection (+ residual) in one launch (S_max <= 64,
-    HD = 128); bit-identical to ``attn_decode_rope`` followed by ``gemv``."""
+    HD = 128); bit-identical to ``attn_decode_rope`` followed by ``gemv``.  ``pos_host``: the position as a host integer (B = 1,
+    S_max <= 32): the launch that issues every load of its prologue at once."""
     B, _, S_max, _ = kcache.shape
     N = W.shape[0]
     assert table.dtype == torch.float32 and table.is_contiguous() and W.shape[1] == H * HD and W.stride(1) == 1 and y.shape == (B, N)
+    if pos_host is not None and B == 1 and S_max <= 32 and H * HD == 1024 and H <= 8:
+        assert qkv.is_contiguous() and y.is_contiguous() and (residual is None or residual.is_contiguous())
+        check(lib.csm_gemv_attn_at_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), int(pos_host), table.data_ptr(), W.data_ptr(),
+                                        y.data_ptr(), _ptr(residual), N, H, KV, HD, S_max, W.stride(0), _stream()), "csm_gemv_attn_at_bf16")
+        return y
     check(lib.csm_gemv_attn_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), pos_i32.data_ptr(), table.data_ptr(),
                                  W.data_ptr(), y.data_ptr(), _ptr(residual), B, N, H, KV, HD, S_max, qkv.stride(0), W.stride(0),
                                  y.stride(0), _stream()), "csm_gemv_attn_bf16")

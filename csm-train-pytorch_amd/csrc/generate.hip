@@ -5,6 +5,23 @@
 
 namespace {
 
+// Probe builds only (-DCSM_DECODE_STAMPS, tools/probes/decode_stamps.sh): the first and the last workgroup of a stamped kernel
+// record the 100 MHz wall clock at a few points; the product build compiles none of this.
+#ifdef CSM_DECODE_STAMPS
+__device__ unsigned long long g_decode_stamps[8192];
+__device__ unsigned int g_decode_nstamp;
+#define STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH(id) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {                          \
+        const unsigned int s0 = atomicAdd(&g_decode_nstamp, 10u);                                                                   \
+        if (s0 + 10 <= 8192) { g_decode_stamps[s0] = (id); g_decode_stamps[s0 + 1] = blockIdx.x;                                    \
+            for (int q_ = 0; q_ < 8; ++q_) g_decode_stamps[s0 + 2 + q_] = st_[q_]; } } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(id)
+#endif
+
 struct ValIdx { float v; int i; };
 
 __device__ __forceinline__ ValIdx vi_max(ValIdx a, ValIdx b) {  // larger value wins, then the lower index
@@ -321,6 +338,8 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int NO = N / RW;
     if (n >= NO) return;
+    STAMP_DECL;
+    STAMP(0);
     // the wave's weight row(s): requested first
     U4 wq[RW][KCH];
     const bf16_t* w = W + (size_t)n * RW * ldw + lane * 8;
@@ -335,6 +354,17 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
     U4 xq[KCH];
 #pragma unroll
     for (int c = 0; c < KCH; ++c) xq[c] = *reinterpret_cast<const U4*>(x + row * ldx + lane * 8 + 512 * c);
+#ifdef CSM_DECODE_STAMPS
+    STAMP(1);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) asm volatile("" : "+v"(xq[c].x), "+v"(xq[c].y), "+v"(xq[c].z), "+v"(xq[c].w));     // x has arrived
+    STAMP(2);
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) asm volatile("" : "+v"(wq[r][c].x), "+v"(wq[r][c].y), "+v"(wq[r][c].z), "+v"(wq[r][c].w));   // weights have arrived
+    STAMP(3);
+#endif
     if (norm_w) {
         float ss = 0.f;
 #pragma unroll
@@ -376,11 +406,14 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
         const float g = bf2f(f2bf(v)), u = bf2f(f2bf(wave_sum(acc[1])));
         v = silu(g) * u;
     }
+    STAMP(4);
     if (lane == 0) {
         if (R) v += bf2f(R[n]);
         if constexpr (sizeof(OutT) == 2) y[n] = f2bf(v);
         else y[n] = v;
     }
+    STAMP(5);
+    STAMP_FLUSH(100 + KCH * 4 + (SWIGLU ? 2 : 0) + (norm_w ? 1 : 0));
 }
 
 // y[b][n] = sum_k x[b][k] * W[k][n]  (weights stored K-major, e.g. audio_head[i] = [d'][V]): a thread owns 8 columns.
@@ -686,8 +719,194 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
     }
 }
 
+// The same layer step for ONE utterance whose position the HOST knows (round 4): the depth decoder's step i is always at position
+// i, so the captured frame graph can carry it as a kernel argument.  With the position in a register every address of the
+// prologue - the RoPE table row, the q|k|v row, the <= 31 cached key rows, the value slices, the first weight row - is known when
+// the wave starts, and all of them are requested at once: one memory round trip instead of the four dependent ones of
+// gemv_attn_kernel (position -> q|k|v row and table -> key rows -> value rows), which were 5 of that kernel's 10 us.
+// The arithmetic is gemv_attn_kernel<1, 128>'s operation for operation (same products, same order, same trees): bit-identical.
+// 512 threads: wave w = q head w in the attention (H <= 8); S_max <= 32 (a frame's codebooks).
+template <int HD>
+__global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restrict__ qkv, bf16_t* kc, bf16_t* vc, int p,
+                                                           const float* __restrict__ table, const bf16_t* __restrict__ W,
+                                                           bf16_t* __restrict__ y, const bf16_t* __restrict__ R, int N, int H, int KV,
+                                                           int S_max, int ldw, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    const int K = H * HD;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem_x);                         // [K]
+    float* qs = reinterpret_cast<float*>(smem_x + (size_t)K * 2);           // [H][HD]
+    float* kn = qs + (size_t)H * HD;                                        // [KV][HD]
+    float* pw = kn + (size_t)KV * HD;                                       // [waves][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rep = H / KV, n = p + 1;
+    constexpr int KCH = 2;
+    constexpr int LPR = HD / 8;
+    const int sub = lane % LPR, gq = lane / LPR;
+    STAMP_DECL;
+    STAMP(0);
+    // ---- every load of the prologue, back to back
+    const int row0 = blockIdx.x * 8 + wave;
+    U4 wq0[KCH] = {};
+    if (row0 < N) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) wq0[c] = *reinterpret_cast<const U4*>(W + (size_t)row0 * ldw + lane * 8 + 512 * c);
+    }
+    const int npair = (H + KV) * (HD / 2);                                  // 640 pairs over 512 threads: two rounds
+    float rc[2], rs[2], rx0[2], rx1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int it = threadIdx.x + 512 * t;
+        rc[t] = rs[t] = rx0[t] = rx1[t] = 0.f;
+        if (it < npair) {
+            const int i = it % (HD / 2), hh = it / (HD / 2);
+            const float2 cs = *reinterpret_cast<const float2*>(table + ((size_t)p * (HD / 2) + i) * 2);
+            const uint32_t xx = *reinterpret_cast<const uint32_t*>(qkv + hh * HD + 2 * i);
+            rc[t] = cs.x; rs[t] = cs.y; rx0[t] = __uint_as_float(xx << 16); rx1[t] = __uint_as_float(xx & 0xffff0000u);
+        }
+    }
+    const int h = wave, kvh = h / rep;                                      // (waves >= H idle through the attention)
+    const bool att = wave < H;
+    const bf16_t* Kc = kc + (size_t)kvh * S_max * HD;
+    const bf16_t* Vc = vc + (size_t)kvh * S_max * HD;
+    const bf16_t* vnew = qkv + (H + KV + kvh) * HD;
+    U4 kq[HD / 8] = {};
+    if (att && lane < p) {
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) kq[c] = *reinterpret_cast<const U4*>(Kc + (size_t)lane * HD + c * 8);
+    }
+    U4 vq[4][2] = {};
+    if (att) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s_ = 4 * r + gq + 16 * u;
+                if (s_ < n) vq[r][u] = *reinterpret_cast<const U4*>((s_ == p ? vnew : Vc + (size_t)s_ * HD) + sub * 8);
+            }
+    }
+    STAMP(1);
+#ifdef CSM_DECODE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (probe: everything requested above has arrived)
+    STAMP(2);
+#endif
+    // ---- RoPE of q and of the new k; workgroup 0 appends k, v to the caches (row p: no load above reads it)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int it = threadIdx.x + 512 * t;
+        if (it < npair) {
+            const int i = it % (HD / 2), hh = it / (HD / 2);
+            const float x0 = rx0[t], x1 = rx1[t], c = rc[t], sn = rs[t];
+            const bf16_t r0 = f2bf(x0 * c - x1 * sn), r1 = f2bf(x1 * c + x0 * sn);
+            if (hh < H) {
+                qs[(size_t)hh * HD + 2 * i] = bf2f(r0); qs[(size_t)hh * HD + 2 * i + 1] = bf2f(r1);
+            } else {
+                const int kh = hh - H;
+                kn[(size_t)kh * HD + 2 * i] = bf2f(r0); kn[(size_t)kh * HD + 2 * i + 1] = bf2f(r1);
+                if (blockIdx.x == 0) {
+                    const bf16_t* vn = qkv + (H + KV + kh) * HD;
+                    const size_t dst = ((size_t)kh * S_max + p) * HD;
+                    kc[dst + 2 * i] = r0; kc[dst + 2 * i + 1] = r1;
+                    vc[dst + 2 * i] = vn[2 * i]; vc[dst + 2 * i + 1] = vn[2 * i + 1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(3);
+    // ---- attention: wave = q head
+    if (att) {
+        const float* q = qs + (size_t)h * HD;
+        const float* knew = kn + (size_t)kvh * HD;
+        float d = 0.f;
+        if (lane < n) {
+            if (lane == p) {
+#pragma unroll 8
+                for (int c = 0; c < HD; ++c) d += q[c] * knew[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < HD / 8; ++c) {
+                    float kf[8];
+                    unpack8(kq[c], kf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += q[c * 8 + j] * kf[j];
+                }
+            }
+            d *= scale;
+        }
+        const float mx = wave_max(lane < n ? d : -INFINITY);
+        const float pr = lane < n ? __expf(d - mx) : 0.f;
+        const float sum = wave_sum(pr);
+        pw[wave * 64 + lane] = pr;
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s_ = 4 * r + gq + 16 * u;
+                if (s_ < n) {
+                    float vf[8];
+                    unpack8(vq[r][u], vf);
+                    const float ps = pw[wave * 64 + s_];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += ps * vf[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] += __shfl_xor(acc[j], LPR, 64);
+                acc[j] += __shfl_xor(acc[j], 2 * LPR, 64);
+                o8[j] += acc[j];
+            }
+        }
+        if (gq == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[h * HD + sub * 8 + j] = f2bf(o8[j] / sum);
+        }
+    }
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+    // ---- y = attention . W^T (+ R): one wave per output row
+    for (int nrow = row0; nrow < N; nrow += gridDim.x * 8) {
+        float acc = 0.f;
+        const bf16_t* w = W + (size_t)nrow * ldw;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int k = lane * 8 + 512 * c;
+            float wf[8], xf[8];
+            unpack8(nrow == row0 ? wq0[c] : *reinterpret_cast<const U4*>(w + k), wf);
+            unpack8(*reinterpret_cast<const U4*>(xs + k), xf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += wf[j] * xf[j];
+        }
+        float v = wave_sum(acc);
+        if (lane == 0) {
+            if (R) v += bf2f(R[nrow]);
+            y[nrow] = f2bf(v);
+        }
+    }
+    STAMP(6);
+    STAMP_FLUSH(200);
+}
+
 }  // namespace
 
+#ifdef CSM_DECODE_STAMPS
+// probe builds: copy out (and reset) the stamp records; returns the number of 10-word records
+extern "C" int csm_decode_stamps(unsigned long long* host, int max_records) {
+    unsigned int n = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_decode_nstamp), sizeof(n));
+    int rec = (int)(n / 10); if (rec > max_records) rec = max_records; if (rec > 819) rec = 819;
+    if (host && rec > 0) (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_decode_stamps), (size_t)rec * 10 * sizeof(unsigned long long));
+    const unsigned int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_decode_nstamp), &zero, sizeof(zero));
+    return rec;
+}
+#endif
 static int g_gemv_reg = 1, g_gemv_nt = 1;       // csm_set_decode_tuning (A/B: tools/probes)
 extern "C" int csm_set_decode_tuning(int key, int value) {
     if (key == 0) g_gemv_reg = value; else if (key == 1) g_gemv_nt = value; else return 1;
@@ -790,6 +1009,22 @@ extern "C" int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache,
 
 // Decoder layer: rotate + cache append + attention over <= 64 cached positions + output projection (+ residual) in ONE launch;
 // bit-identical to csm_attn_decode_rope followed by csm_gemv_bf16 (same arithmetic, see gemv_attn_kernel).  HD = 128 only.
+extern "C" int csm_gemv_attn_at_bf16(const void* qkv, void* kcache, void* vcache, int pos, const float* rope_table, const void* W,
+                                     void* y, const void* residual, int N, int H, int KV, int HD, int S_max, int ldw, hipStream_t stream) {
+    CSM_REQUIRE(qkv && kcache && vcache && rope_table && W && y, "csm_gemv_attn_at_bf16: null pointer");
+    CSM_REQUIRE(N > 0 && H > 0 && H <= 8 && KV > 0 && H % KV == 0 && HD == 128 && H * HD == 1024 && S_max >= 1 && S_max <= 32 && (ldw & 7) == 0,
+                "csm_gemv_attn_at_bf16: unsupported shape (H=%d KV=%d HD=%d S_max=%d: needs H*HD = 1024, HD 128, S_max <= 32)", H, KV, HD, S_max);
+    CSM_REQUIRE(pos >= 0 && pos < S_max, "csm_gemv_attn_at_bf16: position %d outside the cache (%d rows)", pos, S_max);
+    const int K = H * HD;
+    const size_t lds = (size_t)K * 2 + ((size_t)H * HD + (size_t)KV * HD + 512) * sizeof(float);
+    const int grid = N / 8 < 1 ? 1 : (N / 8 > 2048 ? 2048 : N / 8);
+    const float scale = 1.f / sqrtf((float)HD);
+    hipLaunchKernelGGL((gemv_attn_at_kernel<128>), dim3(grid), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                       pos, rope_table, (const bf16_t*)W, (bf16_t*)y, (const bf16_t*)residual, N, H, KV, S_max, ldw, scale);
+    CSM_CHECK_LAUNCH("csm_gemv_attn_at_bf16");
+    return 0;
+}
+
 extern "C" int csm_gemv_attn_bf16(const void* qkv, void* kcache, void* vcache, const int* pos, const float* rope_table, const void* W,
                                   void* y, const void* residual, int B, int N, int H, int KV, int HD, int S_max, int ld_qkv, int ldw,
                                   int ldy, hipStream_t stream) {

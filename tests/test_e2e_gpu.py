@@ -720,6 +720,18 @@ def test_decoder_attention_fused_into_output_projection(dev):
             ops.gemv_attn(qkv, k2, v2, pos, table, W, y3, None, H, KV, hd)        # (append again: same bits; no residual)
             ops.gemv(o, W, y1)
             assert torch.equal(y1, y3)
+            if B == 1:
+                # round 4: the launch that takes the position from the host (the depth decoder's step i is at position i) and
+                # issues every load of its prologue at once - every position of a frame, same bits in output and caches
+                for p in range(S_max):
+                    pos1 = torch.tensor([p], dtype=torch.int32, device=dev)
+                    k3, v3, k4, v4 = kc.to(dev), vc.to(dev), kc.to(dev), vc.to(dev)
+                    ya, yb = torch.empty(1, d, dtype=BF, device=dev), torch.empty(1, d, dtype=BF, device=dev)
+                    ops.attn_decode_rope(qkv, k3, v3, o, pos1, table, H, KV, hd)
+                    ops.gemv(o, W, ya, residual=R)
+                    ops.gemv_attn(qkv, k4, v4, pos1, table, W, yb, R, H, KV, hd, pos_host=p)
+                    assert torch.equal(k3, k4) and torch.equal(v3, v4), f"caches, host position {p}"
+                    assert torch.equal(ya, yb), f"output, host position {p}: {(ya.float() - yb.float()).abs().max().item()}"
 
 
 def test_batched_generation_matches_single(dev):
