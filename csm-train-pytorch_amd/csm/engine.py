@@ -385,6 +385,8 @@ class Engine:
         # called as hook(prefix, layer) right before a forward first reads that bucket's parameters, hook(None, None) before
         # anything else reads parameters (ZeRO-1: the updated shards are all-gathered behind the optimiser step, dp.py)
         self.param_hook = None
+        # a list here makes the cache-free generate path append the logits [B, V] every code is drawn from (parity tests)
+        self.capture_logits = None
 
     def _need(self, group=None, layer=None):
         if self.param_hook is not None:
@@ -761,6 +763,8 @@ class Engine:
 
         def draw(lg, i):
             q = None if noise is None else noise[i].to(dev)
+            if self.capture_logits is not None:                     # (parity tests: the logits each code of the frame was drawn from)
+                self.capture_logits.append(lg[:, :V].clone())
             return sample_topk(lg[:, :V], topk, temperature, q)
 
         c0 = draw(logits, 0)                                         # [B,1] int32

@@ -348,9 +348,8 @@ __global__ __launch_bounds__(256, 3) void attn64_fwd_kernel(const bf16_t* __rest
 __device__ __forceinline__ void unrope2(const float* __restrict__ table, int p, int hd, int pair, float& g0, float& g1, float& g2,
                                         float& g3) {
     const float4 t = *reinterpret_cast<const float4*>(table + ((size_t)p * (hd >> 1) + pair) * 2);   // c0, s0, c1, s1
-    const float a0 = g0 * t.x + g1 * t.y, a1 = g1 * t.x - g0 * t.y;
-    const float a2 = g2 * t.z + g3 * t.w, a3 = g3 * t.z - g2 * t.w;
-    g0 = a0; g1 = a1; g2 = a2; g3 = a3;
+    rope_rot(g0, g1, t.x, -t.y);
+    rope_rot(g2, g3, t.z, -t.w);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -151,9 +151,8 @@ __global__ __launch_bounds__(256, 1) void attn64_dkv_asm_kernel(const bf16_t* __
             float b0 = t1[4 * gq] * mul, b1 = t1[4 * gq + 1] * mul, b2 = t1[4 * gq + 2] * mul, b3 = t1[4 * gq + 3] * mul;
             if (unrope) {                                 // backward of the interleaved-pair rotation (attention.hip: unrope2)
                 const float4 t = ta[gq], u = tb[gq];
-                const float x0 = a0 * t.x + a1 * t.y, x1 = a1 * t.x - a0 * t.y, x2 = a2 * t.z + a3 * t.w, x3 = a3 * t.z - a2 * t.w;
-                const float y0 = b0 * u.x + b1 * u.y, y1 = b1 * u.x - b0 * u.y, y2 = b2 * u.z + b3 * u.w, y3 = b3 * u.z - b2 * u.w;
-                a0 = x0; a1 = x1; a2 = x2; a3 = x3; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
+                rope_rot(a0, a1, t.x, -t.y); rope_rot(a2, a3, t.z, -t.w);
+                rope_rot(b0, b1, u.x, -u.y); rope_rot(b2, b3, u.z, -u.w);
             }
             uint2 w0, w1;
             w0.x = pack2bf(a0, a1); w0.y = pack2bf(a2, a3);
@@ -314,9 +313,8 @@ __global__ __launch_bounds__(256, 1) void attn64_dq_asm_kernel(const bf16_t* __r
             if (rope) {
                 const float* tr = rope + ((size_t)(q0 + 32 * qt + r) * 32 + 4 * gq + 2 * h) * 2;
                 const float4 t = *reinterpret_cast<const float4*>(tr), u = *reinterpret_cast<const float4*>(tr + 32);
-                const float x0 = a0 * t.x + a1 * t.y, x1 = a1 * t.x - a0 * t.y, x2 = a2 * t.z + a3 * t.w, x3 = a3 * t.z - a2 * t.w;
-                const float y0 = b0 * u.x + b1 * u.y, y1 = b1 * u.x - b0 * u.y, y2 = b2 * u.z + b3 * u.w, y3 = b3 * u.z - b2 * u.w;
-                a0 = x0; a1 = x1; a2 = x2; a3 = x3; b0 = y0; b1 = y1; b2 = y2; b3 = y3;
+                rope_rot(a0, a1, t.x, -t.y); rope_rot(a2, a3, t.z, -t.w);
+                rope_rot(b0, b1, u.x, -u.y); rope_rot(b2, b3, u.z, -u.w);
             }
             uint2 w0, w1;
             w0.x = pack2bf(a0, a1); w0.y = pack2bf(a2, a3);

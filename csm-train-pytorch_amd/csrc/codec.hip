@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void rope_half_kernel(float* __restrict__ qkv,
         sincosf((float)(pos0 + t) * inv, &sn, &cs);
         float* p = qkv + (size_t)t * 3 * H * hd + (size_t)hh * hd;
         const float a = p[i], b = p[i + half];
-        p[i] = a * cs - b * sn;
-        p[i + half] = b * cs + a * sn;
+        float ra = a, rb = b;
+        rope_rot(ra, rb, cs, sn);
+        p[i] = ra;
+        p[i + half] = rb;
     }
 }
 

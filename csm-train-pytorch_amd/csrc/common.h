@@ -41,15 +41,53 @@ __device__ __forceinline__ uint32_t pack2bf_pk(float lo, float hi) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float silu(float x) { return x * fast_sigmoid(x); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// torchtune's interleaved-pair rotation of one pair, (x0 c - x1 s, x1 c + x0 s), with every product rounded before the add:
+// the reference evaluates the expression op by op in fp32 (no fused multiply-add), and left to the compiler two inlined copies
+// of the same expression were contracted differently (round 4: one-ulp differences at bf16 ties between the 256 x 256 and the
+// 256 x 192 tile kernels, and between the decode kernels and the prefill path).  EVERY rotation in the library - GEMM
+// epilogues, csm_rope, the decode kernels, the attention backward's transposed rotation (s -> -s), Mimi - goes through this.
+__device__ __forceinline__ void rope_rot(float& x0, float& x1, float c, float s) {
+#pragma clang fp contract(off)
+    const float a0 = x0 * c - x1 * s, a1 = x1 * c + x0 * s;
+    x0 = a0; x1 = a1;
+}
+
+// Cross-lane butterflies without the LDS crossbar (round 4).  __shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip of
+// ~100+ cycles per step, six dependent ones per wave reduction - most of the in-kernel time of the one-row decode kernels
+// (tools/probes/decode_stamps.py) and the tail of every norm / loss kernel.  gfx950 has VALU forms for every step:
+//   xor 32 / xor 16: v_permlane32_swap / v_permlane16_swap with vdst = src = x leave {lower, upper} pairs: own ^ pair[0] ^ pair[1]
+//                    is the partner's value (exact for any x);
+//   xor 8:           DPP row_ror:8 (lane (i + 8) mod 16 of the row = i ^ 8: exact);
+//   xor 2, xor 1:    DPP quad_perm [2,3,0,1], [1,0,3,2] (exact);
+//   xor 4:           DPP row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3 (exact; two moves).
+// lane_xor<O>(x) therefore returns exactly __shfl_xor(x, O, 64): same operands into the same additions (a + b == b + a bit for
+// bit), so every reduction keeps its bits.
+__device__ __forceinline__ uint32_t lane_xor_u32_32(uint32_t x) { auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); return r[0] ^ r[1] ^ x; }
+__device__ __forceinline__ uint32_t lane_xor_u32_16(uint32_t x) { auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); return r[0] ^ r[1] ^ x; }
+template <int O>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x) {
+    static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "lane_xor: power of two below 64");
+    if constexpr (O == 32) return lane_xor_u32_32(x);
+    else if constexpr (O == 16) return lane_xor_u32_16(x);
+    else if constexpr (O == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);        // row_ror:8
+    else if constexpr (O == 4) {
+        int r = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);                                          // row_shl:4 -> lanes 0-3, 8-11
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xa, false);                                              // row_shr:4 -> lanes 4-7, 12-15
+        return (uint32_t)r;
+    } else if constexpr (O == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4e, 0xf, 0xf, false);        // quad_perm [2,3,0,1]
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xb1, 0xf, 0xf, false);                                 // quad_perm [1,0,3,2]
+}
+template <int O> __device__ __forceinline__ float lane_xor(float x) { return __uint_as_float(lane_xor_u32<O>(__float_as_uint(x))); }
+template <int O> __device__ __forceinline__ int lane_xor(int x) { return (int)lane_xor_u32<O>((uint32_t)x); }
+
+__device__ __forceinline__ float wave_sum(float v) {       // the butterfly of `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o)`
+    v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
     return v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, lane_xor<32>(v)); v = fmaxf(v, lane_xor<16>(v)); v = fmaxf(v, lane_xor<8>(v));
+    v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<1>(v));
     return v;
 }
 

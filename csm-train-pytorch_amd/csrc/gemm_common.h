@@ -243,16 +243,6 @@ struct Epi {
 // Llama3ScaledRoPE applied to the fp32 accumulator, one bf16 rounding instead of the stand-alone kernel's two.
 enum { EPI_NONE = 0, EPI_SWIGLU_FWD = 1, EPI_SWIGLU_BWD = 2, EPI_ROPE = 3 };
 
-// one pair through its (cos, sin): x0' = fma(x0, c, -(x1 s)), x1' = fma(x1, c, x0 s), the products x1 s / x0 s rounded first - written out
-// so that every inlined copy of an epilogue rounds the same way (left to the compiler, two copies of the same expression were contracted
-// differently: one-ulp differences at bf16 ties between the 256 x 256 and the 256 x 192 tile kernels, round 4)
-__device__ __forceinline__ void rope_rot(float& x0, float& x1, float c, float s) {
-#pragma clang fp contract(off)
-    const float p = x1 * s, q = x0 * s;
-    const float a0 = __builtin_fmaf(x0, c, -p), a1 = __builtin_fmaf(x1, c, q);
-    x0 = a0; x1 = a1;
-}
-
 // rotate NP adjacent pairs v[0..2NP) that start at column n of row m (n even, all pairs inside one head)
 template <int NP>
 __device__ __forceinline__ void epi_rope(const Epi& e, int m, int n, float* v) {

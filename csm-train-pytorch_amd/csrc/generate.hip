@@ -33,13 +33,9 @@ __device__ __forceinline__ ValIdx vi_min(ValIdx a, ValIdx b) {  // smaller value
 
 template <bool MAX>
 __device__ __forceinline__ ValIdx block_arg(ValIdx x, ValIdx* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ValIdx y;
-        y.v = __shfl_xor(x.v, o, 64);
-        y.i = __shfl_xor(x.i, o, 64);
-        x = MAX ? vi_max(x, y) : vi_min(x, y);
-    }
+#define CSM_ARG_STEP(o) { ValIdx y; y.v = lane_xor<o>(x.v); y.i = lane_xor<o>(x.i); x = MAX ? vi_max(x, y) : vi_min(x, y); }
+    CSM_ARG_STEP(32) CSM_ARG_STEP(16) CSM_ARG_STEP(8) CSM_ARG_STEP(4) CSM_ARG_STEP(2) CSM_ARG_STEP(1)
+#undef CSM_ARG_STEP
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[w] = x;
@@ -69,6 +65,8 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
     const float* x = logits + (size_t)row * ldl;
     const float* qq = q + (size_t)row * V;
     const int wave = threadIdx.x >> 6;
+    STAMP_DECL;
+    STAMP(0);
     float val[NPT];
     uint32_t key[NPT];
     float tmax = -INFINITY;
@@ -80,7 +78,9 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         key[j] = c >= V ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
         tmax = fmaxf(tmax, val[j]);
     }
+    STAMP(1);
     const float top = block_max(tmax, fred);
+    STAMP(2);
     uint32_t prefix = 0u;
     // two bits per round: three trial values, each counted per lane first (vector compares and adds) and then with ONE ballot per
     // bit of the per-lane count (a ballot's scalar result feeds a scalar popcount that waits for it, ~35 ns each: the round's
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         // thread reads the same counts.)
         if (exact) break;
     }
+    STAMP(3);
     const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
     const float kth = __uint_as_float(ku);
     // log_softmax over kept values, then softmax of that (torch evaluates both)
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         if (c < V && val[j] >= kth) s2 += expf(((val[j] - top) - logsum) - ymax);
     }
     s2 = block_sum(s2, fred);
+    STAMP(4);
     ValIdx best = {-INFINITY, 0x7fffffff};
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
@@ -142,8 +144,11 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
             best = vi_max(best, (ValIdx){p / qq[c], c});
         }
     }
+    STAMP(5);
     best = block_arg<true>(best, red);
     if (threadIdx.x == 0) out[row] = best.i;
+    STAMP(6);
+    STAMP_FLUSH(300);
 }
 
 // Mimi split RVQ encode (moshi 0.2.2; call site reference src/csm/generator.py:117).  One block per frame; the
@@ -491,8 +496,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         float c = 1.f, sn = 0.f;
         if (table) { c = table[((size_t)p * (HD / 2) + i) * 2]; sn = table[((size_t)p * (HD / 2) + i) * 2 + 1]; }
         const float q0 = bf2f(q[2 * i]), q1 = bf2f(q[2 * i + 1]), k0 = bf2f(knew[2 * i]), k1 = bf2f(knew[2 * i + 1]);
-        const bf16_t rq0 = f2bf(q0 * c - q1 * sn), rq1 = f2bf(q1 * c + q0 * sn);
-        const bf16_t rk0 = f2bf(k0 * c - k1 * sn), rk1 = f2bf(k1 * c + k0 * sn);
+        float q0r = q0, q1r = q1, k0r = k0, k1r = k1;
+        rope_rot(q0r, q1r, c, sn);
+        rope_rot(k0r, k1r, c, sn);
+        const bf16_t rq0 = f2bf(q0r), rq1 = f2bf(q1r);
+        const bf16_t rk0 = f2bf(k0r), rk1 = f2bf(k1r);
         qs[2 * i] = bf2f(rq0); qs[2 * i + 1] = bf2f(rq1);
         kn[2 * i] = bf2f(rk0); kn[2 * i + 1] = bf2f(rk1);
         if (table && h % rep == 0) {
@@ -544,10 +552,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         for (int j = 0; j < 8; ++j) acc[j] += p * vf[j];
     }
     // reduce the ngrp partials: first inside a wave (groups of a wave differ in lane bits >= log2(LPR)), then across waves
+    static_assert(LPR == 8 || LPR == 16, "head_dim 64 or 128");
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    for (int j = 0; j < 8; ++j) {
+        if constexpr (LPR == 8) acc[j] += lane_xor<8>(acc[j]);
+        acc[j] += lane_xor<16>(acc[j]);
+        acc[j] += lane_xor<32>(acc[j]);
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < LPR)
 #pragma unroll
@@ -603,7 +614,9 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
         const float c = table[((size_t)p * (HD / 2) + i) * 2], sn = table[((size_t)p * (HD / 2) + i) * 2 + 1];
         const bf16_t* src = qkv + (size_t)b * ldq + hh * HD;                 // q heads, then k heads, contiguous in the fused row
         const float x0 = bf2f(src[2 * i]), x1 = bf2f(src[2 * i + 1]);
-        const bf16_t r0 = f2bf(x0 * c - x1 * sn), r1 = f2bf(x1 * c + x0 * sn);
+        float y0 = x0, y1 = x1;
+        rope_rot(y0, y1, c, sn);
+        const bf16_t r0 = f2bf(y0), r1 = f2bf(y1);
         if (hh < H) {
             qs[((size_t)b * H + hh) * HD + 2 * i] = bf2f(r0); qs[((size_t)b * H + hh) * HD + 2 * i + 1] = bf2f(r1);
         } else {
@@ -663,8 +676,8 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                acc[j] += __shfl_xor(acc[j], LPR, 64);
-                acc[j] += __shfl_xor(acc[j], 2 * LPR, 64);
+                acc[j] += lane_xor<LPR>(acc[j]);
+                acc[j] += lane_xor<2 * LPR>(acc[j]);
                 o8[j] += acc[j];                                             // quartets left to right, starting from 0 (0 + W0 is exact)
             }
         }
@@ -796,7 +809,9 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
         if (it < npair) {
             const int i = it % (HD / 2), hh = it / (HD / 2);
             const float x0 = rx0[t], x1 = rx1[t], c = rc[t], sn = rs[t];
-            const bf16_t r0 = f2bf(x0 * c - x1 * sn), r1 = f2bf(x1 * c + x0 * sn);
+            float y0 = x0, y1 = x1;
+            rope_rot(y0, y1, c, sn);
+            const bf16_t r0 = f2bf(y0), r1 = f2bf(y1);
             if (hh < H) {
                 qs[(size_t)hh * HD + 2 * i] = bf2f(r0); qs[(size_t)hh * HD + 2 * i + 1] = bf2f(r1);
             } else {
@@ -856,8 +871,8 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                acc[j] += __shfl_xor(acc[j], LPR, 64);
-                acc[j] += __shfl_xor(acc[j], 2 * LPR, 64);
+                acc[j] += lane_xor<LPR>(acc[j]);
+                acc[j] += lane_xor<2 * LPR>(acc[j]);
                 o8[j] += acc[j];
             }
         }

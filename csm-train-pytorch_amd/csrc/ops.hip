@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
         if (inverse) { sn[0] = -sn[0]; sn[1] = -sn[1]; sn[2] = -sn[2]; sn[3] = -sn[3]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            o[2 * i] = f[2 * i] * cs[i] - f[2 * i + 1] * sn[i];
-            o[2 * i + 1] = f[2 * i + 1] * cs[i] + f[2 * i] * sn[i];
+            o[2 * i] = f[2 * i]; o[2 * i + 1] = f[2 * i + 1];
+            rope_rot(o[2 * i], o[2 * i + 1], cs[i], sn[i]);
         }
         *reinterpret_cast<U4*>(ptr) = pack8(o);
     }

@@ -192,9 +192,9 @@ def test_config5_decode_kernels_at_csm1b_shapes_vs_oracle(dev):
 def test_config5_generate_csm1b_125_frames(dev, csm1b):
     """BASELINE config 5's loop at CSM-1B size: a prompt of 40 text positions + 5 s of context audio (62 frames + EOS frame),
     then 125 frames (10 s) x 32 codebooks through ``Model.generate_frame`` with pinned Exp(1) draws.  Graph replay == eager,
-    bit for bit, over all 125 frames; the frames are valid codes; the prefill frame equals the cache-free recompute path's
-    (same kernels) and the first decode frame - matrix-vector kernels against the KV caches vs. MFMA tiles over the whole
-    prefix - agrees on almost every codebook given the same history and noise."""
+    bit for bit, over all 125 frames; the frames are valid codes; against the cache-free recompute path (MFMA tiles over the
+    whole prefix instead of matrix-vector kernels against the KV caches) the first two frames are equal up to their first
+    difference, which must be a sampler near-tie within bf16 logit error (checked on the recompute path's logits)."""
     m = csm1b
     K, V = m.args.audio_num_codebooks, m.args.audio_vocab_size
     g = torch.Generator().manual_seed(99)
@@ -233,10 +233,43 @@ def test_config5_generate_csm1b_125_frames(dev, csm1b):
         assert int(eager.min()) >= 0 and int(eager.max()) < V
         assert torch.equal(eager, graph), "graph replay must reproduce the eager KV-cache frames bit for bit (125 frames)"
         assert len({tuple(f.flatten().tolist()) for f in eager}) > n_frames // 2, "frames must differ (fresh noise, moving state)"
-        rc = run(False, 2, use_cache=False, history=eager)
-        assert torch.equal(rc[0], eager[0]), "the prefill frame goes through the same kernels in both paths"
-        agree = (rc[1] == eager[1]).float().mean().item()
-        assert agree >= 0.9, f"first decode frame: KV-cache path and recompute path agree on {agree:.0%} of the codebooks"
+        # The cache-free path (prefix recompute through the training kernels: MFMA tiles over the whole history) against the
+        # KV-cache path (matrix-vector kernels) on the first two frames, fed the same history: different reduction orders, so the
+        # logits differ by bf16 rounding and a near-tie of the sampler may go the other way - after which the rest of the frame
+        # conditions on a different code.  Checked property: the frames are equal up to their first difference, and at that
+        # codebook the KV-cache path's pick is a POSSIBLE outcome of the sampler on the recompute path's logits when every logit
+        # may move by the error of bf16 activations (it can make the top-k cut, and every token that would certainly beat it in
+        # the race l / T - log q can be cut out).
+        eng = m._engine
+        eng.capture_logits = []
+        try:
+            rc = run(False, 2, use_cache=False, history=eager)
+            logits = [x.float().cpu() for x in eng.capture_logits]                   # 2 frames x K codebooks, [1, V] each
+        finally:
+            eng.capture_logits = None
+        assert len(logits) == 2 * K
+        topk_, T_ = 50, 0.9
+        n_checked = 0
+        for f in range(2):
+            diff = (rc[f, 0] != eager[f, 0]).nonzero().flatten()
+            if diff.numel() == 0:
+                continue
+            i_star = int(diff[0])
+            lg = logits[f * K + i_star][0].double()
+            qrow = noise[f, i_star, 0].double()
+            r, gk = int(rc[f, 0, i_star]), int(eager[f, 0, i_star])
+            eps = 2.0 ** -7 * max(1.0, float(lg.abs().max()))
+            assert int((lg - eps > lg[gk] + eps).sum()) <= topk_ - 1, (f, i_star, "the KV-cache pick cannot make the top-k cut", float(lg[gk]), float(lg[r]))
+            score_lo = (lg - eps) / T_ - qrow.log()
+            for j in (score_lo > (float(lg[gk]) + eps) / T_ - float(qrow[gk].log())).nonzero().flatten().tolist():
+                if j == gk:
+                    continue
+                others_above = int((lg + eps > lg[j] - eps).sum()) - 1
+                assert others_above >= topk_, (f, i_star, f"token {j} beats the KV-cache pick {gk} by more than the logit error and cannot be "
+                                                          f"cut out: not a near-tie", float(lg[j]), float(lg[gk]), r)
+            n_checked += 1
+        print(f"config 5: recompute vs KV-cache, first two frames: {n_checked} near-tie divergence(s) checked, "
+              f"agreement {[(rc[f] == eager[f]).float().mean().item() for f in range(2)]}")
     finally:
         m.use_hip_graph, m.use_kv_cache = True, True
 

@@ -25,7 +25,7 @@ buf = np.zeros(819 * 10, dtype=np.uint64)
 n = f(buf.ctypes.data, 819)
 rec = buf[:n * 10].reshape(n, 10).astype(np.int64)
 print("records", n)
-names = {200: "attn+wo"}
+names = {200: "attn+wo", 300: "sampler"}
 def nm(i):
     if i in names: return names[i]
     i -= 100; kch, sw, nw = i // 4, (i >> 1) & 1, i & 1
@@ -42,8 +42,8 @@ while i < n:
         grp.append(rec[i + 1]); i += 1
     rows.append(grp); i += 1
 print("launch: kernel | per workgroup (first / last): start [us since first record], then deltas in us between stamps | gap to the next launch's first start")
-lo = max(0, len(rows) // 2 - 20)
-for k in range(lo, min(len(rows), lo + 40)):
+lo = max(0, len(rows) // 2 - 24)
+for k in range(lo, min(len(rows), lo + 48)):
     grp = rows[k]
     out = []
     end = 0
