@@ -47,81 +47,114 @@ __device__ __forceinline__ ValIdx block_arg(ValIdx x, ValIdx* red) {
 
 // reference src/csm/models/model.py:79-96: logits/T, keep values >= k-th largest, log_softmax -> softmax,
 // argmax(p / q) with q ~ Exp(1) supplied by the caller.  One 256-thread block per row, V <= 256 * NPT.
-// The k-th largest value comes from a 32-round bisection on an order-preserving integer image of the floats; a round
-// counts "keys >= trial" with wave ballots + scalar popcounts (no cross-lane shuffles: __shfl_xor is an LDS-crossbar
-// ds_bpermute, six of them per reduction were most of the first version's 26 us) and ONE barrier (the per-wave counts
-// alternate between two LDS slots).  A generated frame draws 32 codes one after the other, so this kernel's latency is
-// paid 32 times per 80 ms of audio.  (Round 3 tried four bits per round - 8 barriers instead of 32, 15 trial values each:
-// 40 us instead of 20.  The ballots, not the barriers, are the cost: each is a vector compare whose scalar result a scalar
-// popcount then waits for, ~70 ns a piece, and the wide round needs 135 of them.)
+// A generated frame draws 32 codes one after the other, so this kernel's latency is paid 32 times per 80 ms of audio; it runs as
+// ONE workgroup on a cold CU, and what it costs is latency, not work (tools/probes/decode_stamps.py, round 4: of 15 us, 4-5
+// were the Exp(1) row arriving from HBM right before the last step, 5-6 the 9-16 rounds of the bisection that found the k-th
+// largest value, 2-3 the logits' own arrival).  So:
+//  * the Exp(1) row is requested first of all and consumed last;
+//  * the k-th largest value comes from an 8-bit radix select on an order-preserving integer image of the floats: per pass the
+//    keys that still match the prefix are counted into a 256-bin LDS histogram (ds_add_u32; four histograms, zeroed once, so a
+//    pass needs ONE barrier), every wave then scans the bins from the top (4 bins per lane, a DPP row scan + three row totals, no
+//    LDS crossbar) and reads the digit, the count above it and the count inside it off the lane that crosses k.  At most four
+//    passes; a pass whose digit leaves exactly the wanted number of keys at or above it ends the search (the kept set is decided:
+//    typical logits separate their 50th and 51st value in the second pass).  Rounds 2-3 used a bisection with ballots: 2 bits per
+//    round, 9-16 rounds of ~0.35 us.
+// The kept set is `key >= threshold` on the integer image - the set `value >= k-th largest` keeps (ties included).
 constexpr int SMP_PER_THREAD = 16;
+__device__ __forceinline__ int dpp_row_shr_add(int v, int ctrl_n) {   // v + (v shifted right by n lanes inside its row of 16, zero fill)
+    switch (ctrl_n) {
+        case 1: return v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+        case 2: return v + __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+        case 4: return v + __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+        default: return v + __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    }
+}
 template <int NPT>
 __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restrict__ logits, const float* __restrict__ q,
                                                           int* __restrict__ out, int V, int ldl, int topk, float temperature) {
     __shared__ ValIdx red[4];
     __shared__ float fred[16];
-    __shared__ int cnt_s[2][4][4];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4][256];
     const int row = blockIdx.x;
     const float* x = logits + (size_t)row * ldl;
     const float* qq = q + (size_t)row * V;
-    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     STAMP_DECL;
     STAMP(0);
-    float val[NPT];
+    float qv[NPT], val[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        val[j] = c < V ? x[c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        qv[j] = c < V ? qq[c] : 1.f;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) hist[ps][threadIdx.x] = 0u;
     uint32_t key[NPT];
     float tmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int c = threadIdx.x + 256 * j;
-        val[j] = c < V ? x[c] / temperature : -INFINITY;
+        val[j] = c < V ? val[j] / temperature : -INFINITY;
         const uint32_t u = __float_as_uint(val[j]);
         key[j] = c >= V ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
         tmax = fmaxf(tmax, val[j]);
     }
     STAMP(1);
-    const float top = block_max(tmax, fred);
+    const float top = block_max(tmax, fred);               // (its barriers also publish the zeroed histograms)
     STAMP(2);
     uint32_t prefix = 0u;
-    // two bits per round: three trial values, each counted per lane first (vector compares and adds) and then with ONE ballot per
-    // bit of the per-lane count (a ballot's scalar result feeds a scalar popcount that waits for it, ~35 ns each: the round's
-    // cost is ~0.3 us of barrier + LDS exchange plus its ballots, so 16 rounds x 12 ballots beat both 32 x 9 and 8 x 60)
-    for (int shift = 30, rnd = 0; shift >= 0; shift -= 2, ++rnd) {
-        int c[3];                                        // wave-uniform counts
+    int krem = topk;                                        // keys still wanted among those that match the prefix
+#pragma unroll 1
+    for (int ps = 0; ps < 4; ++ps) {
+        const int shift = 24 - 8 * ps;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const uint32_t trial = prefix | ((uint32_t)(d + 1) << shift);
-            int cl = 0;
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) cl += key[j] >= trial ? 1 : 0;
-            c[d] = 0;
-#pragma unroll
-            for (int bb = 0; (1 << bb) <= NPT; ++bb) c[d] += __popcll(__ballot((cl >> bb) & 1)) << bb;
+        for (int j = 0; j < NPT; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            const bool in = c < V && (ps == 0 || (key[j] >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (in) atomicAdd(&hist[ps][(key[j] >> shift) & 255u], 1u);
         }
-        if ((threadIdx.x & 63) < 3) cnt_s[rnd & 1][wave][threadIdx.x & 63] = (threadIdx.x & 63) == 0 ? c[0] : (threadIdx.x & 63) == 1 ? c[1] : c[2];
         __syncthreads();
-        int digit = 0;                                   // counts fall as the trial grows: the largest digit that still has >= k keys
-        bool exact = false;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int tot = cnt_s[rnd & 1][0][d] + cnt_s[rnd & 1][1][d] + cnt_s[rnd & 1][2][d] + cnt_s[rnd & 1][3][d];
-            if (tot >= topk) { digit = d + 1; exact = tot == topk; }
+        // lane l owns bins 252 - 4l .. 255 - 4l; the scan runs from the top bin down (every wave does it: no second barrier)
+        const uint4 hv = *reinterpret_cast<const uint4*>(&hist[ps][252 - 4 * lane]);
+        const int b3 = (int)hv.w, b2 = (int)hv.z, b1 = (int)hv.y, b0 = (int)hv.x;      // bins 255-4l, 254-4l, 253-4l, 252-4l
+        const int mine = b3 + b2 + b1 + b0;
+        int pre = mine;
+        pre = dpp_row_shr_add(pre, 1); pre = dpp_row_shr_add(pre, 2); pre = dpp_row_shr_add(pre, 4); pre = dpp_row_shr_add(pre, 8);
+        const int t0 = __builtin_amdgcn_readlane(pre, 15), t1 = __builtin_amdgcn_readlane(pre, 31), t2 = __builtin_amdgcn_readlane(pre, 47);
+        pre += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);     // keys in my bins and every bin above them
+        int above = pre - mine, digit, inside;
+        if (above + b3 >= krem) { digit = 255 - 4 * lane; inside = b3; }
+        else {
+            above += b3;
+            if (above + b2 >= krem) { digit = 254 - 4 * lane; inside = b2; }
+            else {
+                above += b2;
+                if (above + b1 >= krem) { digit = 253 - 4 * lane; inside = b1; }
+                else { above += b1; digit = 252 - 4 * lane; inside = b0; }
+            }
         }
+        const unsigned long long cross = __ballot(pre >= krem);
+        const int L = cross ? __ffsll((long long)cross) - 1 : 63;                       // (never empty: the matching keys number >= krem)
+        digit = __builtin_amdgcn_readlane(digit, L);
+        above = __builtin_amdgcn_readlane(above, L);
+        inside = __builtin_amdgcn_readlane(inside, L);
         prefix |= (uint32_t)digit << shift;
-        // exactly k keys at or above this trial: the kept set is decided (it is what `value >= k-th largest` keeps - with a tie at
-        // the k-th value no count is ever exactly k and the search runs to the last bit), the remaining bits cannot change it.
-        // Typical logits separate their 50th and 51st value after ~18 bits: 9 rounds instead of 16.  (Block-uniform: every
-        // thread reads the same counts.)
-        if (exact) break;
+        const bool exact = above + inside == krem;          // exactly k keys at or above this prefix: the kept set is decided
+        krem -= above;
+        if (exact) break;                                   // (block-uniform: every wave read the same histogram)
     }
     STAMP(3);
-    const uint32_t ku = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
-    const float kth = __uint_as_float(ku);
     // log_softmax over kept values, then softmax of that (torch evaluates both)
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int c = threadIdx.x + 256 * j;
-        if (c < V && val[j] >= kth) s += expf(val[j] - top);
+        if (c < V && key[j] >= prefix) s += expf(val[j] - top);
     }
     s = block_sum(s, fred);
     const float logsum = logf(s);
@@ -130,7 +163,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int c = threadIdx.x + 256 * j;
-        if (c < V && val[j] >= kth) s2 += expf(((val[j] - top) - logsum) - ymax);
+        if (c < V && key[j] >= prefix) s2 += expf(((val[j] - top) - logsum) - ymax);
     }
     s2 = block_sum(s2, fred);
     STAMP(4);
@@ -140,8 +173,8 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         const int c = threadIdx.x + 256 * j;
         if (c < V) {
             float p = 0.f;
-            if (val[j] >= kth) p = expf(((val[j] - top) - logsum) - ymax) / s2;
-            best = vi_max(best, (ValIdx){p / qq[c], c});
+            if (key[j] >= prefix) p = expf(((val[j] - top) - logsum) - ymax) / s2;
+            best = vi_max(best, (ValIdx){p / qv[j], c});
         }
     }
     STAMP(5);
@@ -332,7 +365,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
 // in the same order as gemv_kernel<1, ...> (bit-identical: tests/test_e2e_gpu.py decode checks).  NT: non-temporal weight loads
 // for matrices that are streamed once per frame (the backbone's 1.9 GB), so that they do not push the depth decoder's 222 MB -
 // re-read 31 times per frame - out of the Infinity Cache.
-template <int KCH, typename OutT, bool SWIGLU, bool NT>
+// RPW (round 4): outputs per wave.  The w13 product of the depth decoder (K = 1024, 4096 gate/up pairs) ran one pair per wave -
+// 8192 waves that each normalised x again, and the launch was bound by VALU issue, not memory (tools/probes/decode_stamps.py:
+// ~300 instructions per wave, 8 waves per SIMD = 4.6 us; the 16 MB of weights need 3).  Four pairs per wave share one
+// normalisation, and a pair's two row sums share one butterfly: v_permlane32_swap(gate, up) leaves the gate partials in lanes 0-31
+// and the up partials in lanes 32-63, the remaining xor-16 .. xor-1 steps never cross the halves - the same additions as two
+// separate wave_sum() calls, so the same bits.
+template <int KCH, typename OutT, bool SWIGLU, bool NT, int RPW = 1>
 __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
                                                        const bf16_t* __restrict__ R, int N, int ldw, int ldx, int ldy,
                                                        const bf16_t* __restrict__ norm_w, float eps, const int* __restrict__ row_index,
@@ -340,21 +379,24 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
     constexpr int K = 512 * KCH;
     constexpr int RW = SWIGLU ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;
     const int NO = N / RW;
-    if (n >= NO) return;
+    if (n0 >= NO) return;
     STAMP_DECL;
     STAMP(0);
-    // the wave's weight row(s): requested first
-    U4 wq[RW][KCH];
-    const bf16_t* w = W + (size_t)n * RW * ldw + lane * 8;
+    // the wave's weight rows: requested first (outputs past the end re-read the last one and are never stored)
+    U4 wq[RPW][RW][KCH];
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+    for (int o = 0; o < RPW; ++o) {
+        const bf16_t* w = W + (size_t)min(n0 + o, NO - 1) * RW * ldw + lane * 8;
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            const U4* p = reinterpret_cast<const U4*>(w + (size_t)r * ldw + 512 * c);
-            wq[r][c] = NT ? __builtin_nontemporal_load(p) : *p;
-        }
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const U4* p = reinterpret_cast<const U4*>(w + (size_t)r * ldw + 512 * c);
+                wq[o][r][c] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+    }
     const size_t row = row_index ? (size_t)(row_index[0] + row_offset) : (size_t)0;
     U4 xq[KCH];
 #pragma unroll
@@ -365,9 +407,11 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
     for (int c = 0; c < KCH; ++c) asm volatile("" : "+v"(xq[c].x), "+v"(xq[c].y), "+v"(xq[c].z), "+v"(xq[c].w));     // x has arrived
     STAMP(2);
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+    for (int o = 0; o < RPW; ++o)
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) asm volatile("" : "+v"(wq[r][c].x), "+v"(wq[r][c].y), "+v"(wq[r][c].z), "+v"(wq[r][c].w));   // weights have arrived
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) asm volatile("" : "+v"(wq[o][r][c].x), "+v"(wq[o][r][c].y), "+v"(wq[o][r][c].z), "+v"(wq[o][r][c].w));   // weights have arrived
     STAMP(3);
 #endif
     if (norm_w) {
@@ -391,31 +435,46 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
             xq[c] = pack8(f);
         }
     }
-    float acc[RW];
+    float acc[RPW][RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+    for (int o = 0; o < RPW; ++o)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[o][r] = 0.f;
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         float xf[8];
         unpack8(xq[c], xf);
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            float wf[8];
-            unpack8(wq[r][c], wf);
+        for (int o = 0; o < RPW; ++o)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r] += wf[j] * xf[j];
-        }
-    }
-    float v = wave_sum(acc[0]);
-    if constexpr (SWIGLU) {
-        const float g = bf2f(f2bf(v)), u = bf2f(f2bf(wave_sum(acc[1])));
-        v = silu(g) * u;
+            for (int r = 0; r < RW; ++r) {
+                float wf[8];
+                unpack8(wq[o][r][c], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][r] += wf[j] * xf[j];
+            }
     }
     STAMP(4);
-    if (lane == 0) {
-        if (R) v += bf2f(R[n]);
-        if constexpr (sizeof(OutT) == 2) y[n] = f2bf(v);
-        else y[n] = v;
+#pragma unroll
+    for (int o = 0; o < RPW; ++o) {
+        float v;
+        if constexpr (SWIGLU) {
+            // both row sums in one butterfly: gate partials to lanes 0-31, up partials to lanes 32-63, then xor 16 .. 1 inside the halves
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[o][0]), __float_as_uint(acc[o][1]), false, false);
+            float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            t += lane_xor<16>(t); t += lane_xor<8>(t); t += lane_xor<4>(t); t += lane_xor<2>(t); t += lane_xor<1>(t);
+            const float gs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+            const float us = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 32));
+            const float g = bf2f(f2bf(gs)), u = bf2f(f2bf(us));
+            v = silu(g) * u;
+        } else {
+            v = wave_sum(acc[o][0]);
+        }
+        if (lane == 0 && n0 + o < NO) {
+            if (R) v += bf2f(R[n0 + o]);
+            if constexpr (sizeof(OutT) == 2) y[n0 + o] = f2bf(v);
+            else y[n0 + o] = v;
+        }
     }
     STAMP(5);
     STAMP_FLUSH(100 + KCH * 4 + (SWIGLU ? 2 : 0) + (norm_w ? 1 : 0));
@@ -735,21 +794,30 @@ __global__ __launch_bounds__(512) void gemv_attn_kernel(const bf16_t* __restrict
 // The same layer step for ONE utterance whose position the HOST knows (round 4): the depth decoder's step i is always at position
 // i, so the captured frame graph can carry it as a kernel argument.  With the position in a register every address of the
 // prologue - the RoPE table row, the q|k|v row, the <= 31 cached key rows, the value slices, the first weight row - is known when
-// the wave starts, and all of them are requested at once: one memory round trip instead of the four dependent ones of
-// gemv_attn_kernel (position -> q|k|v row and table -> key rows -> value rows), which were 5 of that kernel's 10 us.
-// The arithmetic is gemv_attn_kernel<1, 128>'s operation for operation (same products, same order, same trees): bit-identical.
-// 512 threads: wave w = q head w in the attention (H <= 8); S_max <= 32 (a frame's codebooks).
+// the wave starts, and all of them are requested at once: one memory round trip instead of the dependent chain of
+// gemv_attn_kernel (position -> q|k|v row and table -> key rows -> value rows).  The cached key rows are fetched as contiguous
+// 16-byte chunks (512 threads x 16 B = a kv head's 31 rows in one coalesced request each; `lane = key` loads touched 32 cache lines
+// per instruction and took 1.9 us to issue, tools/probes/decode_stamps.py) and re-read from LDS in the lane = key layout (row
+// stride 272 B: conflict-free); the rotated new key is written into the same LDS image, so that lane takes the same code path
+// instead of a divergent serial dot product.  The arithmetic is gemv_attn_kernel<1, 128>'s operation for operation (same products,
+// same order, same trees): bit-identical.  512 threads: wave w = q head w in the attention (H <= 8); S_max <= 32 (a frame's codebooks).
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load (its fence is
+// s_waitcnt vmcnt(0)), which here would pull the prefetched value slices and the weight row - needed last - in front of the first
+// barrier.  The compiler still counts vmcnt for the registers those loads fill.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int HD>
 __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restrict__ qkv, bf16_t* kc, bf16_t* vc, int p,
                                                            const float* __restrict__ table, const bf16_t* __restrict__ W,
                                                            bf16_t* __restrict__ y, const bf16_t* __restrict__ R, int N, int H, int KV,
                                                            int S_max, int ldw, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    constexpr int KROW = HD * 2 + 16;                                       // bytes per key row of the LDS image
     const int K = H * HD;
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem_x);                         // [K]
     float* qs = reinterpret_cast<float*>(smem_x + (size_t)K * 2);           // [H][HD]
-    float* kn = qs + (size_t)H * HD;                                        // [KV][HD]
-    float* pw = kn + (size_t)KV * HD;                                       // [waves][64]
+    float* pw = qs + (size_t)H * HD;                                        // [waves][64]
+    char* ks = reinterpret_cast<char*>(pw + 512);                           // [KV][32][KROW] key rows 0 .. p (row p: the new, rotated key)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rep = H / KV, n = p + 1;
     constexpr int KCH = 2;
@@ -757,13 +825,9 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
     const int sub = lane % LPR, gq = lane / LPR;
     STAMP_DECL;
     STAMP(0);
-    // ---- every load of the prologue, back to back
+    // ---- every load of the prologue, back to back, in the order they are consumed (loads return in order: the weight row, which
+    //      comes from furthest away and is needed last, goes last)
     const int row0 = blockIdx.x * 8 + wave;
-    U4 wq0[KCH] = {};
-    if (row0 < N) {
-#pragma unroll
-        for (int c = 0; c < KCH; ++c) wq0[c] = *reinterpret_cast<const U4*>(W + (size_t)row0 * ldw + lane * 8 + 512 * c);
-    }
     const int npair = (H + KV) * (HD / 2);                                  // 640 pairs over 512 threads: two rounds
     float rc[2], rs[2], rx0[2], rx1[2];
 #pragma unroll
@@ -777,16 +841,18 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
             rc[t] = cs.x; rs[t] = cs.y; rx0[t] = __uint_as_float(xx << 16); rx1[t] = __uint_as_float(xx & 0xffff0000u);
         }
     }
+    // cached key rows 0 .. p-1 of both kv heads: thread t = 16-byte chunk t of the head's contiguous rows (HD / 8 chunks per row)
+    U4 kg[2] = {};
+    const bool kld = (int)threadIdx.x < p * (HD / 8);
+    if (kld) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+            if (kh < KV) kg[kh] = *reinterpret_cast<const U4*>(kc + (size_t)kh * S_max * HD + (size_t)threadIdx.x * 8);
+    }
     const int h = wave, kvh = h / rep;                                      // (waves >= H idle through the attention)
     const bool att = wave < H;
-    const bf16_t* Kc = kc + (size_t)kvh * S_max * HD;
     const bf16_t* Vc = vc + (size_t)kvh * S_max * HD;
     const bf16_t* vnew = qkv + (H + KV + kvh) * HD;
-    U4 kq[HD / 8] = {};
-    if (att && lane < p) {
-#pragma unroll
-        for (int c = 0; c < HD / 8; ++c) kq[c] = *reinterpret_cast<const U4*>(Kc + (size_t)lane * HD + c * 8);
-    }
     U4 vq[4][2] = {};
     if (att) {
 #pragma unroll
@@ -797,26 +863,37 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
                 if (s_ < n) vq[r][u] = *reinterpret_cast<const U4*>((s_ == p ? vnew : Vc + (size_t)s_ * HD) + sub * 8);
             }
     }
+    U4 wq0[KCH] = {};
+    if (row0 < N) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) wq0[c] = *reinterpret_cast<const U4*>(W + (size_t)row0 * ldw + lane * 8 + 512 * c);
+    }
     STAMP(1);
 #ifdef CSM_DECODE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (probe: everything requested above has arrived)
     STAMP(2);
 #endif
-    // ---- RoPE of q and of the new k; workgroup 0 appends k, v to the caches (row p: no load above reads it)
+    // ---- the key image; RoPE of q and of the new k (-> row p of the image); workgroup 0 appends k, v to the caches (row p: no
+    //      load above reads it)
+    if (kld) {
+        const int row = threadIdx.x / (HD / 8), ch = threadIdx.x % (HD / 8);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+            if (kh < KV) *reinterpret_cast<U4*>(ks + ((size_t)kh * 32 + row) * KROW + ch * 16) = kg[kh];
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int it = threadIdx.x + 512 * t;
         if (it < npair) {
             const int i = it % (HD / 2), hh = it / (HD / 2);
-            const float x0 = rx0[t], x1 = rx1[t], c = rc[t], sn = rs[t];
-            float y0 = x0, y1 = x1;
-            rope_rot(y0, y1, c, sn);
+            float y0 = rx0[t], y1 = rx1[t];
+            rope_rot(y0, y1, rc[t], rs[t]);
             const bf16_t r0 = f2bf(y0), r1 = f2bf(y1);
             if (hh < H) {
                 qs[(size_t)hh * HD + 2 * i] = bf2f(r0); qs[(size_t)hh * HD + 2 * i + 1] = bf2f(r1);
             } else {
                 const int kh = hh - H;
-                kn[(size_t)kh * HD + 2 * i] = bf2f(r0); kn[(size_t)kh * HD + 2 * i + 1] = bf2f(r1);
+                *reinterpret_cast<uint32_t*>(ks + ((size_t)kh * 32 + p) * KROW + 4 * i) = (uint32_t)r0 | ((uint32_t)r1 << 16);
                 if (blockIdx.x == 0) {
                     const bf16_t* vn = qkv + (H + KV + kh) * HD;
                     const size_t dst = ((size_t)kh * S_max + p) * HD;
@@ -826,25 +903,20 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
-    // ---- attention: wave = q head
+    // ---- attention: wave = q head, lane = key
     if (att) {
         const float* q = qs + (size_t)h * HD;
-        const float* knew = kn + (size_t)kvh * HD;
         float d = 0.f;
         if (lane < n) {
-            if (lane == p) {
-#pragma unroll 8
-                for (int c = 0; c < HD; ++c) d += q[c] * knew[c];
-            } else {
+            const char* krow = ks + ((size_t)kvh * 32 + lane) * KROW;
 #pragma unroll
-                for (int c = 0; c < HD / 8; ++c) {
-                    float kf[8];
-                    unpack8(kq[c], kf);
+            for (int c = 0; c < HD / 8; ++c) {
+                float kf[8];
+                unpack8(*reinterpret_cast<const U4*>(krow + c * 16), kf);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) d += q[c * 8 + j] * kf[j];
-                }
+                for (int j = 0; j < 8; ++j) d += q[c * 8 + j] * kf[j];
             }
             d *= scale;
         }
@@ -852,12 +924,12 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
         const float pr = lane < n ? __expf(d - mx) : 0.f;
         const float sum = wave_sum(pr);
         pw[wave * 64 + lane] = pr;
-        float o8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+        static_assert(LPR == 16, "the row-packed reduction below assumes one 16-lane row per key group");
+        float acc[4][8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s_ = 4 * r + gq + 16 * u;
@@ -866,15 +938,24 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
                     unpack8(vq[r][u], vf);
                     const float ps = pw[wave * 64 + s_];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += ps * vf[j];
+                    for (int j = 0; j < 8; ++j) acc[r][j] += ps * vf[j];
                 }
             }
+        }
+        // The four quartets' group sums ((g0 + g1) + (g2 + g3)) share their swaps: v_permlane16_swap(quartet a, quartet b) + add
+        // leaves a's g0 + g1 / g2 + g3 in rows 0 / 2 and b's in rows 1 / 3; v_permlane32_swap of two such registers + add leaves quartet
+        // r's total in row r.  Row 0 then adds them left to right: ((T0 + T1) + T2) + T3 - gemv_attn_kernel's sums, operand for
+        // operand (o8 = 0 + T0 is exact), in 21 instructions per column instead of 44.
+        float o8[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[j] += lane_xor<LPR>(acc[j]);
-                acc[j] += lane_xor<2 * LPR>(acc[j]);
-                o8[j] += acc[j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][j]), __float_as_uint(acc[1][j]), false, false);
+            auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2][j]), __float_as_uint(acc[3][j]), false, false);
+            const float y = __uint_as_float(s01[0]) + __uint_as_float(s01[1]), z = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);
+            auto st = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(z), false, false);
+            const float T = __uint_as_float(st[0]) + __uint_as_float(st[1]);         // row r: quartet r's total
+            const float p2 = lane_xor<32>(T);                                        // row 0: T2, row 1: T3
+            o8[j] = ((T + lane_xor<16>(T)) + p2) + lane_xor<16>(p2);                 // (row 0 only is meaningful)
         }
         if (gq == 0) {
 #pragma unroll
@@ -882,7 +963,7 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
         }
     }
     STAMP(4);
-    __syncthreads();
+    lds_barrier();
     STAMP(5);
     // ---- y = attention . W^T (+ R): one wave per output row
     for (int nrow = row0; nrow < N; nrow += gridDim.x * 8) {
@@ -922,9 +1003,11 @@ extern "C" int csm_decode_stamps(unsigned long long* host, int max_records) {
     return rec;
 }
 #endif
-static int g_gemv_reg = 1, g_gemv_nt = 1;       // csm_set_decode_tuning (A/B: tools/probes)
+// (g_gemv_rpw: gate/up pairs per wave in the depth decoder's w13 product.  Measured at 1 / 2 / 4: 207.5 / 207.5 / 204 frames/s -
+//  that launch streams 32 MB and is bound by its loads, not by the per-wave normalisation: one pair per wave stays the default)
+static int g_gemv_reg = 1, g_gemv_nt = 1, g_gemv_rpw = 1;       // csm_set_decode_tuning (A/B: tools/probes)
 extern "C" int csm_set_decode_tuning(int key, int value) {
-    if (key == 0) g_gemv_reg = value; else if (key == 1) g_gemv_nt = value; else return 1;
+    if (key == 0) g_gemv_reg = value; else if (key == 1) g_gemv_nt = value; else if (key == 2) g_gemv_rpw = value; else return 1;
     return 0;
 }
 static int gemv_launch(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
@@ -938,11 +1021,21 @@ static int gemv_launch(const void* x, const void* W, void* y, const void* residu
     if (B == 1 && g_gemv_reg && (K == 1024 || K == 2048 || K == 8192)) {
         // one batch row: x in registers, no LDS, no barrier (gemv_reg_kernel); matrices of the 2048-wide stack are streamed once
         // per frame: non-temporal
-        const int grid = (no + 3) / 4;
+        int grid = (no + 3) / 4;
         const bool nt = g_gemv_nt && (K == 2048 || (K == 8192 && N == 2048));
 #define LR(KCH, T, SW, NT_) hipLaunchKernelGGL((gemv_reg_kernel<KCH, T, SW, NT_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset)
 #define LK(T, SW, NT_) do { if (K == 1024) LR(2, T, SW, NT_); else if (K == 2048) LR(4, T, SW, NT_); else LR(16, T, SW, NT_); } while (0)
-        if (swiglu) { if (nt) LK(bf16_t, true, true); else LK(bf16_t, true, false); }
+        if (swiglu && K == 1024 && !nt && g_gemv_rpw > 1 && no >= 2048) {
+            // the depth decoder's w13: several gate/up pairs per wave (one normalisation of x per wave instead of per pair)
+            if (g_gemv_rpw == 2) {
+                grid = (no + 7) / 8;
+                hipLaunchKernelGGL((gemv_reg_kernel<2, bf16_t, true, false, 2>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W, (bf16_t*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset);
+            } else {
+                grid = (no + 15) / 16;
+                hipLaunchKernelGGL((gemv_reg_kernel<2, bf16_t, true, false, 4>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W, (bf16_t*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset);
+            }
+        }
+        else if (swiglu) { if (nt) LK(bf16_t, true, true); else LK(bf16_t, true, false); }
         else if (out_f32) { if (nt) LK(float, false, true); else LK(float, false, false); }
         else { if (nt) LK(bf16_t, false, true); else LK(bf16_t, false, false); }
 #undef LK
@@ -1027,11 +1120,11 @@ extern "C" int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache,
 extern "C" int csm_gemv_attn_at_bf16(const void* qkv, void* kcache, void* vcache, int pos, const float* rope_table, const void* W,
                                      void* y, const void* residual, int N, int H, int KV, int HD, int S_max, int ldw, hipStream_t stream) {
     CSM_REQUIRE(qkv && kcache && vcache && rope_table && W && y, "csm_gemv_attn_at_bf16: null pointer");
-    CSM_REQUIRE(N > 0 && H > 0 && H <= 8 && KV > 0 && H % KV == 0 && HD == 128 && H * HD == 1024 && S_max >= 1 && S_max <= 32 && (ldw & 7) == 0,
+    CSM_REQUIRE(N > 0 && H > 0 && H <= 8 && KV > 0 && KV <= 2 && H % KV == 0 && HD == 128 && H * HD == 1024 && S_max >= 1 && S_max <= 32 && (ldw & 7) == 0,
                 "csm_gemv_attn_at_bf16: unsupported shape (H=%d KV=%d HD=%d S_max=%d: needs H*HD = 1024, HD 128, S_max <= 32)", H, KV, HD, S_max);
     CSM_REQUIRE(pos >= 0 && pos < S_max, "csm_gemv_attn_at_bf16: position %d outside the cache (%d rows)", pos, S_max);
     const int K = H * HD;
-    const size_t lds = (size_t)K * 2 + ((size_t)H * HD + (size_t)KV * HD + 512) * sizeof(float);
+    const size_t lds = (size_t)K * 2 + ((size_t)H * HD + 512) * sizeof(float) + (size_t)KV * 32 * (HD * 2 + 16);
     const int grid = N / 8 < 1 ? 1 : (N / 8 > 2048 ? 2048 : N / 8);
     const float scale = 1.f / sqrtf((float)HD);
     hipLaunchKernelGGL((gemv_attn_at_kernel<128>), dim3(grid), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
