@@ -812,17 +812,19 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
                                                            bf16_t* __restrict__ y, const bf16_t* __restrict__ R, int N, int H, int KV,
                                                            int S_max, int ldw, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
-    constexpr int KROW = HD * 2 + 16;                                       // bytes per key row of the LDS image
+    static_assert(HD == 128, "lane = column pair in the P.V phase");
+    constexpr int KROW = HD * 2 + 16;                                       // bytes per key row of the LDS image (conflict-free lane = key reads)
+    constexpr int VROW = HD * 2;                                            // value rows are read lane = column pair: no padding
     const int K = H * HD;
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem_x);                         // [K]
     float* qs = reinterpret_cast<float*>(smem_x + (size_t)K * 2);           // [H][HD]
-    float* pw = qs + (size_t)H * HD;                                        // [waves][64]
-    char* ks = reinterpret_cast<char*>(pw + 512);                           // [KV][32][KROW] key rows 0 .. p (row p: the new, rotated key)
+    float* pw = qs + (size_t)H * HD;                                        // [8][32] probabilities (un-normalised), then [8] their sums
+    float* psum = pw + 256;
+    char* ks = reinterpret_cast<char*>(psum + 8);                           // [KV][32][KROW] key rows 0 .. p (row p: the new, rotated key)
+    char* vs = ks + (size_t)KV * 32 * KROW;                                 // [KV][32][VROW] value rows 0 .. p
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rep = H / KV, n = p + 1;
     constexpr int KCH = 2;
-    constexpr int LPR = HD / 8;
-    const int sub = lane % LPR, gq = lane / LPR;
     STAMP_DECL;
     STAMP(0);
     // ---- every load of the prologue, back to back, in the order they are consumed (loads return in order: the weight row, which
@@ -830,6 +832,7 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
     const int row0 = blockIdx.x * 8 + wave;
     const int npair = (H + KV) * (HD / 2);                                  // 640 pairs over 512 threads: two rounds
     float rc[2], rs[2], rx0[2], rx1[2];
+    uint32_t rv[2] = {0u, 0u};                                              // (k-head pairs: the new value's pair beside it)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int it = threadIdx.x + 512 * t;
@@ -838,30 +841,20 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
             const int i = it % (HD / 2), hh = it / (HD / 2);
             const float2 cs = *reinterpret_cast<const float2*>(table + ((size_t)p * (HD / 2) + i) * 2);
             const uint32_t xx = *reinterpret_cast<const uint32_t*>(qkv + hh * HD + 2 * i);
+            if (hh >= H) rv[t] = *reinterpret_cast<const uint32_t*>(qkv + (hh + KV) * HD + 2 * i);
             rc[t] = cs.x; rs[t] = cs.y; rx0[t] = __uint_as_float(xx << 16); rx1[t] = __uint_as_float(xx & 0xffff0000u);
         }
     }
-    // cached key rows 0 .. p-1 of both kv heads: thread t = 16-byte chunk t of the head's contiguous rows (HD / 8 chunks per row)
-    U4 kg[2] = {};
+    // cached key / value rows 0 .. p-1 of both kv heads: thread t = 16-byte chunk t of the head's contiguous rows (HD / 8 chunks per row)
+    U4 kg[2] = {}, vg[2] = {};
     const bool kld = (int)threadIdx.x < p * (HD / 8);
     if (kld) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
             if (kh < KV) kg[kh] = *reinterpret_cast<const U4*>(kc + (size_t)kh * S_max * HD + (size_t)threadIdx.x * 8);
-    }
-    const int h = wave, kvh = h / rep;                                      // (waves >= H idle through the attention)
-    const bool att = wave < H;
-    const bf16_t* Vc = vc + (size_t)kvh * S_max * HD;
-    const bf16_t* vnew = qkv + (H + KV + kvh) * HD;
-    U4 vq[4][2] = {};
-    if (att) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int s_ = 4 * r + gq + 16 * u;
-                if (s_ < n) vq[r][u] = *reinterpret_cast<const U4*>((s_ == p ? vnew : Vc + (size_t)s_ * HD) + sub * 8);
-            }
+        for (int kh = 0; kh < 2; ++kh)
+            if (kh < KV) vg[kh] = *reinterpret_cast<const U4*>(vc + (size_t)kh * S_max * HD + (size_t)threadIdx.x * 8);
     }
     U4 wq0[KCH] = {};
     if (row0 < N) {
@@ -873,14 +866,8 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (probe: everything requested above has arrived)
     STAMP(2);
 #endif
-    // ---- the key image; RoPE of q and of the new k (-> row p of the image); workgroup 0 appends k, v to the caches (row p: no
-    //      load above reads it)
-    if (kld) {
-        const int row = threadIdx.x / (HD / 8), ch = threadIdx.x % (HD / 8);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-            if (kh < KV) *reinterpret_cast<U4*>(ks + ((size_t)kh * 32 + row) * KROW + ch * 16) = kg[kh];
-    }
+    // ---- RoPE of q and of the new k (-> row p of the key image; the new value -> row p of the value image); workgroup 0 appends
+    //      k, v to the caches (row p: no load above reads it); then the cached rows into the images
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int it = threadIdx.x + 512 * t;
@@ -893,24 +880,37 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
                 qs[(size_t)hh * HD + 2 * i] = bf2f(r0); qs[(size_t)hh * HD + 2 * i + 1] = bf2f(r1);
             } else {
                 const int kh = hh - H;
-                *reinterpret_cast<uint32_t*>(ks + ((size_t)kh * 32 + p) * KROW + 4 * i) = (uint32_t)r0 | ((uint32_t)r1 << 16);
+                const uint32_t kk = (uint32_t)r0 | ((uint32_t)r1 << 16);
+                *reinterpret_cast<uint32_t*>(ks + ((size_t)kh * 32 + p) * KROW + 4 * i) = kk;
+                *reinterpret_cast<uint32_t*>(vs + ((size_t)kh * 32 + p) * VROW + 4 * i) = rv[t];
                 if (blockIdx.x == 0) {
-                    const bf16_t* vn = qkv + (H + KV + kh) * HD;
-                    const size_t dst = ((size_t)kh * S_max + p) * HD;
-                    kc[dst + 2 * i] = r0; kc[dst + 2 * i + 1] = r1;
-                    vc[dst + 2 * i] = vn[2 * i]; vc[dst + 2 * i + 1] = vn[2 * i + 1];
+                    const size_t dst = ((size_t)kh * S_max + p) * HD + 2 * i;
+                    *reinterpret_cast<uint32_t*>(kc + dst) = kk;
+                    *reinterpret_cast<uint32_t*>(vc + dst) = rv[t];
                 }
             }
         }
     }
+    if (kld) {
+        const int row = threadIdx.x / (HD / 8), ch = threadIdx.x % (HD / 8);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+            if (kh < KV) {
+                *reinterpret_cast<U4*>(ks + ((size_t)kh * 32 + row) * KROW + ch * 16) = kg[kh];
+                *reinterpret_cast<U4*>(vs + ((size_t)kh * 32 + row) * VROW + ch * 16) = vg[kh];
+            }
+    }
     lds_barrier();
     STAMP(3);
-    // ---- attention: wave = q head, lane = key
-    if (att) {
-        const float* q = qs + (size_t)h * HD;
+    // ---- scores + softmax: waves 0 .. H/2-1, two heads of one kv group per wave (lanes 0-31: head 2w, lanes 32-63: head 2w+1;
+    //      lane & 31 = key).  attn_decode_kernel's arithmetic: a serial dot over HD per key; max and sum as 64-lane butterflies whose
+    //      xor-32 step meets only -inf / 0 there (at most 32 keys) and is an identity - the xor-16 .. xor-1 steps stay inside a half.
+    if (wave < H / 2) {
+        const int hh = 2 * wave + (lane >> 5), key = lane & 31, kvh = hh / rep;
+        const float* q = qs + (size_t)hh * HD;
         float d = 0.f;
-        if (lane < n) {
-            const char* krow = ks + ((size_t)kvh * 32 + lane) * KROW;
+        if (key < n) {
+            const char* krow = ks + ((size_t)kvh * 32 + key) * KROW;
 #pragma unroll
             for (int c = 0; c < HD / 8; ++c) {
                 float kf[8];
@@ -920,49 +920,49 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
             }
             d *= scale;
         }
-        const float mx = wave_max(lane < n ? d : -INFINITY);
-        const float pr = lane < n ? __expf(d - mx) : 0.f;
-        const float sum = wave_sum(pr);
-        pw[wave * 64 + lane] = pr;
-        static_assert(LPR == 16, "the row-packed reduction below assumes one 16-lane row per key group");
-        float acc[4][8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int s_ = 4 * r + gq + 16 * u;
-                if (s_ < n) {
-                    float vf[8];
-                    unpack8(vq[r][u], vf);
-                    const float ps = pw[wave * 64 + s_];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[r][j] += ps * vf[j];
-                }
-            }
-        }
-        // The four quartets' group sums ((g0 + g1) + (g2 + g3)) share their swaps: v_permlane16_swap(quartet a, quartet b) + add
-        // leaves a's g0 + g1 / g2 + g3 in rows 0 / 2 and b's in rows 1 / 3; v_permlane32_swap of two such registers + add leaves quartet
-        // r's total in row r.  Row 0 then adds them left to right: ((T0 + T1) + T2) + T3 - gemv_attn_kernel's sums, operand for
-        // operand (o8 = 0 + T0 is exact), in 21 instructions per column instead of 44.
-        float o8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][j]), __float_as_uint(acc[1][j]), false, false);
-            auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2][j]), __float_as_uint(acc[3][j]), false, false);
-            const float y = __uint_as_float(s01[0]) + __uint_as_float(s01[1]), z = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);
-            auto st = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(z), false, false);
-            const float T = __uint_as_float(st[0]) + __uint_as_float(st[1]);         // row r: quartet r's total
-            const float p2 = lane_xor<32>(T);                                        // row 0: T2, row 1: T3
-            o8[j] = ((T + lane_xor<16>(T)) + p2) + lane_xor<16>(p2);                 // (row 0 only is meaningful)
-        }
-        if (gq == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xs[h * HD + sub * 8 + j] = f2bf(o8[j] / sum);
-        }
+        float mx = key < n ? d : -INFINITY;
+        mx = fmaxf(mx, lane_xor<16>(mx)); mx = fmaxf(mx, lane_xor<8>(mx)); mx = fmaxf(mx, lane_xor<4>(mx));
+        mx = fmaxf(mx, lane_xor<2>(mx)); mx = fmaxf(mx, lane_xor<1>(mx));
+        const float pr = key < n ? __expf(d - mx) : 0.f;
+        float sum = pr;
+        sum += lane_xor<16>(sum); sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
+        pw[hh * 32 + key] = pr;
+        if (key == 0) psum[hh] = sum;
     }
     STAMP(4);
+    lds_barrier();
+    // ---- P.V: wave = head, lane = column pair, no cross-lane traffic.  The reference order per column (attn_decode_kernel): 16 key
+    //      groups (quartet r, group g: keys 4r + g and 4r + g + 16, accumulated from 0 by fused multiply-adds), a quartet's groups
+    //      summed (g0 + g1) + (g2 + g3), the quartets added left to right starting from 0 - evaluated here by ONE lane per column
+    //      pair instead of 4 x 16 lanes and two cross-lane sums per quartet: the same operations on the same operands.
+    if (wave < H) {
+        const int h = wave, kvh = h / rep;
+        const float* ph = pw + h * 32;
+        const char* vcol = vs + (size_t)kvh * 32 * VROW + lane * 4;
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a0[4], a1[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                a0[g4] = 0.f; a1[g4] = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int s_ = 4 * r + g4 + 16 * u;
+                    if (s_ < n) {                                            // (uniform: n is a launch argument)
+                        const uint32_t vv = *reinterpret_cast<const uint32_t*>(vcol + (size_t)s_ * VROW);
+                        const float ps = ph[s_];
+                        a0[g4] = __builtin_fmaf(ps, __uint_as_float(vv << 16), a0[g4]);
+                        a1[g4] = __builtin_fmaf(ps, __uint_as_float(vv & 0xffff0000u), a1[g4]);
+                    }
+                }
+            }
+            o0 += (a0[0] + a0[1]) + (a0[2] + a0[3]);
+            o1 += (a1[0] + a1[1]) + (a1[2] + a1[3]);
+        }
+        const float sum = psum[h];
+        *reinterpret_cast<uint32_t*>(xs + h * HD + 2 * lane) = (uint32_t)f2bf(o0 / sum) | ((uint32_t)f2bf(o1 / sum) << 16);
+    }
     lds_barrier();
     STAMP(5);
     // ---- y = attention . W^T (+ R): one wave per output row
@@ -1120,11 +1120,11 @@ extern "C" int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache,
 extern "C" int csm_gemv_attn_at_bf16(const void* qkv, void* kcache, void* vcache, int pos, const float* rope_table, const void* W,
                                      void* y, const void* residual, int N, int H, int KV, int HD, int S_max, int ldw, hipStream_t stream) {
     CSM_REQUIRE(qkv && kcache && vcache && rope_table && W && y, "csm_gemv_attn_at_bf16: null pointer");
-    CSM_REQUIRE(N > 0 && H > 0 && H <= 8 && KV > 0 && KV <= 2 && H % KV == 0 && HD == 128 && H * HD == 1024 && S_max >= 1 && S_max <= 32 && (ldw & 7) == 0,
+    CSM_REQUIRE(N > 0 && H > 0 && H <= 8 && (H & 1) == 0 && KV > 0 && KV <= 2 && H % KV == 0 && ((H / KV) & 1) == 0 && HD == 128 && H * HD == 1024 && S_max >= 1 && S_max <= 32 && (ldw & 7) == 0,
                 "csm_gemv_attn_at_bf16: unsupported shape (H=%d KV=%d HD=%d S_max=%d: needs H*HD = 1024, HD 128, S_max <= 32)", H, KV, HD, S_max);
     CSM_REQUIRE(pos >= 0 && pos < S_max, "csm_gemv_attn_at_bf16: position %d outside the cache (%d rows)", pos, S_max);
     const int K = H * HD;
-    const size_t lds = (size_t)K * 2 + ((size_t)H * HD + 512) * sizeof(float) + (size_t)KV * 32 * (HD * 2 + 16);
+    const size_t lds = (size_t)K * 2 + ((size_t)H * HD + 256 + 8) * sizeof(float) + (size_t)KV * 32 * (HD * 2 + 16) + (size_t)KV * 32 * HD * 2;
     const int grid = N / 8 < 1 ? 1 : (N / 8 > 2048 ? 2048 : N / 8);
     const float scale = 1.f / sqrtf((float)HD);
     hipLaunchKernelGGL((gemv_attn_at_kernel<128>), dim3(grid), dim3(512), lds, stream, (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
