@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         tmax = fmaxf(tmax, val[j]);
     }
     STAMP(1);
-    const float top = block_max(tmax, fred);               // (its barriers also publish the zeroed histograms)
+    __syncthreads();                                        // the zeroed histograms
     STAMP(2);
     uint32_t prefix = 0u;
     int krem = topk;                                        // keys still wanted among those that match the prefix
@@ -149,6 +149,57 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const float* __restric
         if (exact) break;                                   // (block-uniform: every wave read the same histogram)
     }
     STAMP(3);
+    // ---- the kept values (k of them, more only with ties at the threshold) are compacted - in index order of (thread, slot), by a
+    //      block-wide prefix sum of the per-thread counts: deterministic - and ONE wave evaluates log_softmax -> softmax -> p / q ->
+    //      argmax on them: two wave butterflies instead of seven block-wide reductions with their fourteen barriers, and 1 exp per
+    //      kept value instead of 9 per thread.  Tokens outside the kept set have p = 0 and can never win the race (the largest
+    //      kept p is >= 1 / count).  More than 64 kept values (ties, or topk > 64): the block-wide form below.
+    __shared__ float cval[64], cq[64];
+    __shared__ int cidx[64];
+    __shared__ int wtot[4];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) mine += (threadIdx.x + 256 * j < V && key[j] >= prefix) ? 1 : 0;
+    int pre = mine;
+    pre = dpp_row_shr_add(pre, 1); pre = dpp_row_shr_add(pre, 2); pre = dpp_row_shr_add(pre, 4); pre = dpp_row_shr_add(pre, 8);
+    {
+        const int t0 = __builtin_amdgcn_readlane(pre, 15), t1 = __builtin_amdgcn_readlane(pre, 31), t2 = __builtin_amdgcn_readlane(pre, 47);
+        pre += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+    }
+    if (lane == 63) wtot[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    const int w_ = threadIdx.x >> 6;
+    const int before = (w_ > 0 ? wtot[0] : 0) + (w_ > 1 ? wtot[1] : 0) + (w_ > 2 ? wtot[2] : 0);
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (total <= 64) {                                      // (block-uniform)
+        int at = before + pre - mine;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < V && key[j] >= prefix) { cval[at] = val[j]; cq[at] = qv[j]; cidx[at] = c; ++at; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const bool on = lane < total;
+            const float v = on ? cval[lane] : -INFINITY;
+            const float top = wave_max(v);
+            const float e1 = on ? expf(v - top) : 0.f;
+            const float logsum = logf(wave_sum(e1));
+            const float ymax = (top - top) - logsum;
+            const float e2 = on ? expf(((v - top) - logsum) - ymax) : 0.f;
+            const float s2 = wave_sum(e2);
+            ValIdx best = {-INFINITY, 0x7fffffff};
+            if (on) best = (ValIdx){(e2 / s2) / cq[lane], cidx[lane]};
+#define CSM_ARG_STEP(o) { ValIdx y; y.v = lane_xor<o>(best.v); y.i = lane_xor<o>(best.i); best = vi_max(best, y); }
+            CSM_ARG_STEP(32) CSM_ARG_STEP(16) CSM_ARG_STEP(8) CSM_ARG_STEP(4) CSM_ARG_STEP(2) CSM_ARG_STEP(1)
+#undef CSM_ARG_STEP
+            if (lane == 0) out[row] = best.i;
+        }
+        STAMP(6);
+        STAMP_FLUSH(300);
+        return;
+    }
+    const float top = block_max(tmax, fred);
     // log_softmax over kept values, then softmax of that (torch evaluates both)
     float s = 0.f;
 #pragma unroll
