@@ -141,7 +141,11 @@ constexpr bool AAB_G = CSM_ATT_ABLATE & 1, AAB_V = CSM_ATT_ABLATE & 2, AAB_L = C
 // forward (BWD=false) and dQ (BWD=true) share one skeleton: block = 64*QT queries of one (b, h); wave = QT tiles of
 // 16 queries, so every K / V fragment read from LDS feeds QT MFMAs.  K/V tiles are double-buffered in LDS
 // (global -> registers one key block ahead -> LDS after the compute), one barrier per key block.
-template <int HD, bool BWD, int QT>
+// GRP (round 4, short sequences: S <= 16 QT, four q heads per kv head - the depth decoder's 32-position frames): a workgroup is one
+// (batch, kv head) pair and wave w takes ALL queries of q head w of the group, so the four waves share one staging of the
+// group's K / V (the block-per-head mapping staged them once per head and left half of every workgroup's waves without queries).
+// Every query tile still sees the same key tiles in the same order: the same bits.
+template <int HD, bool BWD, int QT, bool GRP = false>
 __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, const bf16_t* __restrict__ dout,
                                                      float* __restrict__ delta, bf16_t* __restrict__ dqkv,
@@ -175,17 +179,18 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
             local = (comb % rep_) * nqblk + within / ncomb;
         }
     }
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (GRP) { pair = blockIdx.x; local = 0; }
     const int qb = nqblk - 1 - (local % nqblk);
     const int kvh_ = pair % KV, b = pair / KV;
-    const int h = kvh_ * rep_ + local / nqblk;
+    const int h = GRP ? kvh_ * rep_ + wave : kvh_ * rep_ + local / nqblk;
     const int kvh = kvh_;
     const int ld = (H + 2 * KV) * HD;
     const bf16_t* Qp = qkv + (size_t)b * S * ld + h * HD;
     const bf16_t* Kp = qkv + (size_t)b * S * ld + (H + kvh) * HD;
     const bf16_t* Vp = qkv + (size_t)b * S * ld + (H + KV + kvh) * HD;
-    const int lane = threadIdx.x & 63, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q_base = qb * 64 * QT;
+    const int q_base = GRP ? 0 : qb * 64 * QT;
     const float c2 = scale * 1.4426950408889634f;
 
     int r0[QT], qrow[QT];
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
     float nlse2[QT], my_delta[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        r0[qt] = q_base + (wave * QT + qt) * 16;
+        r0[qt] = GRP ? qt * 16 : q_base + (wave * QT + qt) * 16;
         qrow[qt] = r0[qt] + (lane & 15);
         const int qc = qrow[qt] < S ? qrow[qt] : S - 1;
         load_rowfrags<HD>(Qp, ld, qc, qf[qt], lane);
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_q_kernel(const bf16_t* __restrict
         for (int i = 0; i < NDT; ++i) o[qt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    int last = q_base + 64 * QT - 1;
+    int last = GRP ? 16 * QT - 1 : q_base + 64 * QT - 1;
     last = last < S ? last : S - 1;
     const int nkb = last / 64 + 1;
     U4 kreg[NST], vreg[NST];
@@ -561,18 +566,19 @@ static int check_attn(const char* name, int B, int S, int H, int KV, int HD) {
 }
 
 static int g_attn_dkv_map = 3, g_attn_dkv_kt1 = 1, g_attn_q_lpt = 1;   // scheduling switches (csm_set_attn_variant)
-template <int HD, bool BWD, int QT>
+template <int HD, bool BWD, int QT, bool GRP = false>
 static void launch_q(const void* qkv, void* out, float* lse, const void* dout, float* delta, void* dqkv, int B, int S,
                      int H, int KV, float scale, hipStream_t stream, const float* rope = nullptr) {
     constexpr int lds = 2 * 2 * Img<HD>::BYTES;
-    auto k = attn_q_kernel<HD, BWD, QT>;
+    auto k = attn_q_kernel<HD, BWD, QT, GRP>;
     static bool done = false;
     if (!done && lds > 65536) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
     done = true;
-    dim3 grid((unsigned)(((S + 64 * QT - 1) / (64 * QT)) * H * B)), block(256);
+    dim3 grid(GRP ? (unsigned)(KV * B) : (unsigned)(((S + 64 * QT - 1) / (64 * QT)) * H * B)), block(256);
     hipLaunchKernelGGL(k, grid, block, lds, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, (const bf16_t*)dout, delta,
                        (bf16_t*)dqkv, S, H, KV, scale, g_attn_q_lpt, rope);
 }
+static int g_attn_grp = 1;      // csm_set_attn_variant bit 14 switches the grouped short-sequence mapping off (A/B)
 
 template <int HD, int KT>
 static void launch_dkv(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int S, int H,
@@ -625,6 +631,7 @@ extern "C" int csm_set_attn_variant(int v) {
     g_attn_dq_asm = (v >> 12) & 1;                   // bit 12: the asm dQ kernel instead of the second-generation one (see above)
     g_attn64_dq_asm_order = (v >> 13) & 1;           // bit 13: asm dQ kernel one query block per workgroup (not persistent)
     g_attn64_dkv_asm_order = (v >> 11) & 1;          // bit 11: asm dK/dV kernel walks an XCD's (batch, kv head) pairs one after the other
+    g_attn_grp = !((v >> 14) & 1);                   // bit 14: head_dim 128, S <= 32: block-per-head mapping instead of the grouped one
     return 0;
 }
 
@@ -638,6 +645,8 @@ extern "C" int csm_attn_fwd(const void* qkv, void* out, float* lse, int B, int S
     } else if (HD == 64) {
         if (S > 64 && g_attn_qt_fwd == 2) launch_q<64, false, 2>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
         else launch_q<64, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
+    } else if (g_attn_grp && S <= 32 && H == 4 * KV) {
+        launch_q<128, false, 2, true>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
     } else {
         launch_q<128, false, 1>(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, KV, scale, stream);
     }
@@ -668,7 +677,8 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
         } else if (g_attn_dkv_kt1) launch_dkv<64, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         else launch_dkv<64, 2>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
     } else {
-        launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        if (g_attn_grp && S <= 32 && H == 4 * KV) launch_q<128, true, 2, true>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
+        else launch_q<128, true, 1>(qkv, o, l, dout, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
         CSM_CHECK_LAUNCH("csm_attn_bwd(dq)");
         launch_dkv<128, 1>(qkv, dout, lse, delta_ws, dqkv, B, S, H, KV, scale, stream, rope);
     }

@@ -683,6 +683,44 @@ def test_attention(dev, B, S, H, KV, hd):
     assert torch.equal(fused[:, (H + KV) * hd:], dqkv[:, (H + KV) * hd:])
 
 
+@pytest.mark.parametrize("B,S,H,KV", [(5, 32, 8, 2), (3, 17, 4, 1), (512, 32, 8, 2)])
+def test_attention_short_sequences_grouped_mapping(dev, B, S, H, KV):
+    """Round 4: head_dim 128, S <= 32 and four q heads per kv head (the depth decoder's 32-position frames) - forward and dQ
+    run with one workgroup per (batch, kv head), wave = q head, so the group's K / V are staged once and no wave is left without
+    queries.  Against the fp32 oracle, and bit-equal to the block-per-head mapping (csm_set_attn_variant bit 14) in output, lse,
+    dQ / dK / dV, with and without the RoPE^T epilogue: every query tile sees the same key tiles in the same order."""
+    from csm.hip import ops
+    from csm.models.model import llama3_rope_table
+    hd = 128
+    g = torch.Generator().manual_seed(11 * S + B)
+    qkv = rnd((B * S, (H + 2 * KV) * hd), g)
+    dout = rnd((B * S, H * hd), g)
+    table = llama3_rope_table(S, hd, 500000.0, 32.0).to(dev).contiguous()
+    qd, dd = qkv.to(dev), dout.to(dev)
+    res = {}
+    try:
+        for name, word in (("grouped", 0), ("per_head", 1 << 14)):
+            ops.lib.csm_set_attn_variant(word | 2 | (1 << 2) | (3 << 4) | (1 << 6) | (1 << 7) if word else 0)
+            out = torch.empty(B * S, H * hd, dtype=BF, device=dev)
+            lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+            ops.attn_fwd(qd, out, lse, B, S, H, KV, hd)
+            dqkv, fused = torch.zeros_like(qd), torch.zeros_like(qd)
+            delta = torch.empty(2, B, H, S, dtype=torch.float32, device=dev)
+            ops.attn_bwd(qd, out, dd, lse, dqkv, delta, B, S, H, KV, hd)
+            ops.attn_bwd(qd, out, dd, lse, fused, delta, B, S, H, KV, hd, rope_table=table)
+            res[name] = (out, lse, dqkv, fused)
+    finally:
+        ops.lib.csm_set_attn_variant(0)
+    for a, b, what in zip(res["grouped"], res["per_head"], ("out", "lse", "dqkv", "dqkv + rope^T")):
+        assert torch.equal(a, b), what
+    if B <= 8:
+        qr = qkv.float().requires_grad_(True)
+        ref = _attn_ref(qr, B, S, H, KV, hd)
+        ref.backward(dout.float())
+        close("attn fwd (grouped)", res["grouped"][0], ref, 1.5e-2)
+        close("attn dqkv (grouped)", res["grouped"][2], qr.grad, 2e-2)
+
+
 def test_attention_spike(dev):
     """One key dominates one query row late in the sequence: forces the online-softmax rescale path."""
     from csm.hip import ops
