@@ -430,7 +430,8 @@ def gemv_attn(qkv, kcache, vcache, pos_i32, table, W, y, residual, H, KV, HD, po
     B, _, S_max, _ = kcache.shape
     N = W.shape[0]
     assert table.dtype == torch.float32 and table.is_contiguous() and W.shape[1] == H * HD and W.stride(1) == 1 and y.shape == (B, N)
-    if pos_host is not None and B == 1 and S_max <= 32 and H * HD == 1024 and H <= 8:
+    if (pos_host is not None and B == 1 and S_max <= 32 and HD == 128 and H * HD == 1024 and H <= 8 and KV <= 2
+            and H % 2 == 0 and (H // KV) % 2 == 0):
         assert qkv.is_contiguous() and y.is_contiguous() and (residual is None or residual.is_contiguous())
         check(lib.csm_gemv_attn_at_bf16(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), int(pos_host), table.data_ptr(), W.data_ptr(),
                                         y.data_ptr(), _ptr(residual), N, H, KV, HD, S_max, W.stride(0), _stream()), "csm_gemv_attn_at_bf16")
