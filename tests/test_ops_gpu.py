@@ -848,6 +848,22 @@ def test_sampler_golden(dev):
     out = torch.empty(64, dtype=torch.int32, device=dev)
     ops.sample_topk(pad.to(dev), qq.to(dev), out, 50, 0.9, V=2051)
     assert torch.equal(out.cpu(), O.sample_topk(lg, 50, 0.9, qq).view(-1))
+    # round 4: the kept values are compacted and finished by one wave when there are at most 64 of them; more (topk > 64, or ties
+    # at the k-th value - torch keeps every value >= the k-th largest) take the block-wide form.  Both against the oracle:
+    # topk 64 (the last one-wave case), 65 and 200 (block-wide), and rows whose k-th value is shared by many tokens.
+    for topk in (1, 2, 64, 65, 200):
+        ops.sample_topk(pad.to(dev), qq.to(dev), out, topk, 0.9, V=2051)
+        assert torch.equal(out.cpu(), O.sample_topk(lg, topk, 0.9, qq).view(-1)), topk
+    tied = lg.clone()
+    tied[:, 100:400] = tied[:, 100:101]                        # 300 equal values per row ...
+    tied[:32, 100:400] += 3.0                                  # ... in half of the rows inside the top 50 (kept set of ~330), below it in the others
+    pad[:, :2051] = tied
+    ops.sample_topk(pad.to(dev), qq.to(dev), out, 50, 0.9, V=2051)
+    assert torch.equal(out.cpu(), O.sample_topk(tied, 50, 0.9, qq).view(-1)), "ties at the k-th value"
+    quant = (lg * 4).round() / 4                               # heavy ties everywhere (values on a 0.25 grid)
+    pad[:, :2051] = quant
+    ops.sample_topk(pad.to(dev), qq.to(dev), out, 50, 0.9, V=2051)
+    assert torch.equal(out.cpu(), O.sample_topk(quant, 50, 0.9, qq).view(-1)), "quantised logits"
 
 
 def test_rvq(dev):
