@@ -101,7 +101,7 @@ for _name, (_args, _res) in _SIGS.items():
 EXPORTS = tuple(_SIGS)
 if os.environ.get("CSM_ATTN_VARIANT"):                  # kernel A/B only (tools/probes): csm_set_attn_variant word
     lib.csm_set_attn_variant(int(os.environ["CSM_ATTN_VARIANT"], 0))
-if os.environ.get("CSM_DECODE_TUNING"):                 # "reg,nt,rpw" e.g. "1,1,2": kernel A/B only (tools/probes)
+if os.environ.get("CSM_DECODE_TUNING"):                 # "reg,nt,rpw,regn" e.g. "1,1,1,0": kernel A/B only (tools/probes)
     for _k, _v in enumerate(os.environ["CSM_DECODE_TUNING"].split(",")):
         lib.csm_set_decode_tuning(_k, int(_v))
 if os.environ.get("CSM_GEMM256_PERSISTENT") == "0":     # kernel A/B only (tools/probes)

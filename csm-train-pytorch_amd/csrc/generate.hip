@@ -416,12 +416,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
 // in the same order as gemv_kernel<1, ...> (bit-identical: tests/test_e2e_gpu.py decode checks).  NT: non-temporal weight loads
 // for matrices that are streamed once per frame (the backbone's 1.9 GB), so that they do not push the depth decoder's 222 MB -
 // re-read 31 times per frame - out of the Infinity Cache.
-// RPW (round 4): outputs per wave.  The w13 product of the depth decoder (K = 1024, 4096 gate/up pairs) ran one pair per wave -
-// 8192 waves that each normalised x again, and the launch was bound by VALU issue, not memory (tools/probes/decode_stamps.py:
-// ~300 instructions per wave, 8 waves per SIMD = 4.6 us; the 16 MB of weights need 3).  Four pairs per wave share one
-// normalisation, and a pair's two row sums share one butterfly: v_permlane32_swap(gate, up) leaves the gate partials in lanes 0-31
-// and the up partials in lanes 32-63, the remaining xor-16 .. xor-1 steps never cross the halves - the same additions as two
-// separate wave_sum() calls, so the same bits.
+// RPW (round 4): outputs per wave.  The w13 product of the depth decoder (K = 1024, 8192 gate/up pairs, 32 MB) runs one pair per
+// wave; two and four pairs per wave (one normalisation of x per wave instead of per pair) were measured at 207.5 / 204 against
+// 207.5 frames/s - the launch is bound by its weight stream - so 1 stays the default (csm_set_decode_tuning(2, n)).  A pair's two
+// row sums share one butterfly: v_permlane32_swap(gate, up) leaves the gate partials in lanes 0-31 and the up partials in lanes
+// 32-63, the remaining xor-16 .. xor-1 steps never cross the halves - the same additions as two separate wave_sum() calls, so the
+// same bits.
 template <int KCH, typename OutT, bool SWIGLU, bool NT, int RPW = 1>
 __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
                                                        const bf16_t* __restrict__ R, int N, int ldw, int ldx, int ldy,
@@ -529,6 +529,132 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
     }
     STAMP(5);
     STAMP_FLUSH(100 + KCH * 4 + (SWIGLU ? 2 : 0) + (norm_w ? 1 : 0));
+}
+
+// Two to four batch rows with x in registers (round 4; generate_batch): wave b of a workgroup prepares row b of x (RMSNorm as a
+// wave reduction, rounded to bf16 exactly as gemv_kernel leaves it in LDS) and publishes it as fp32 behind ONE barrier; every wave
+// then keeps ALL rows of the elements it multiplies in registers, so a weight chunk is unpacked once and feeds NB fused
+// multiply-adds per element, two rows per v_pk_fma_f32 - 24 instructions per 16 bytes of weights at NB = 4, what one row costs -
+// instead of re-reading and re-unpacking every row's x from LDS behind three barriers (gemv_kernel<4>: 8.5 us where the one-row
+// kernel takes 4.6).  (Every wave preparing all rows itself - no LDS, no barrier - was slower than gemv_kernel: 419 against 439
+// frames/s aggregate at B = 4; the preparation is ~130 instructions per row, the products of a K = 1024 row only ~50.)  K = 1024 /
+// 2048; K = 8192 stays with gemv_kernel.  Every (row, output) accumulator sees gemv_kernel's products in gemv_kernel's order:
+// bit-identical per row to the one-row kernels (test_batched_matrix_vector_kernels_match_single_row).
+typedef float csm_f2 __attribute__((ext_vector_type(2)));
+template <int KCH, int NB, typename OutT, bool SWIGLU, bool NT>
+__global__ __launch_bounds__(256) void gemv_regn_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
+                                                        const bf16_t* __restrict__ R, int N, int ldw, int ldx, int ldy,
+                                                        const bf16_t* __restrict__ norm_w, float eps, const int* __restrict__ row_index,
+                                                        int row_offset) {
+    constexpr int K = 512 * KCH;
+    constexpr int RW = SWIGLU ? 2 : 1;
+    constexpr int NP = (NB + 1) / 2;                                        // row pairs (the last one half empty for odd NB)
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int NO = N / RW;
+    const bool live = n < NO;                              // (every wave reaches the barrier; rows past the end re-read the last one)
+    U4 wq[RW][KCH];
+    const bf16_t* w = W + (size_t)(live ? n : NO - 1) * RW * ldw + lane * 8;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const U4* p = reinterpret_cast<const U4*>(w + (size_t)r * ldw + 512 * c);
+            wq[r][c] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+    // wave b < NB prepares row b of x (RMSNorm as a wave reduction, rounded to bf16 as gemv_kernel's LDS copy is) and publishes it
+    // as fp32; ONE barrier; every lane then takes the elements it multiplies, two rows per register pair
+    __shared__ __attribute__((aligned(16))) float xsh[NB][K];
+    const int wv = threadIdx.x >> 6;
+    if (wv < NB) {
+        const int b = wv;
+        const size_t row = row_index ? (size_t)(row_index[b] + row_offset) : (size_t)b;
+        U4 xr[KCH];
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) xr[c] = *reinterpret_cast<const U4*>(x + row * ldx + lane * 8 + 512 * c);
+        float rsn = 1.f;
+        if (norm_w) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                float f[8];
+                unpack8(xr[c], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+            }
+            ss = wave_sum(ss);
+            rsn = rsqrtf(ss / (float)K + eps);
+        }
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            float f[8];
+            unpack8(xr[c], f);
+            if (norm_w) {
+                float w8[8];
+                unpack8(*reinterpret_cast<const U4*>(norm_w + lane * 8 + 512 * c), w8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = f[j] * rsn * w8[j];
+                unpack8(pack8(f), f);                                        // the bf16 rounding gemv_kernel's LDS copy carries
+            }
+            *reinterpret_cast<float4*>(&xsh[b][lane * 8 + 512 * c]) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(&xsh[b][lane * 8 + 512 * c + 4]) = make_float4(f[4], f[5], f[6], f[7]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (LDS only: the weight rows stay in flight)
+    csm_f2 xp[NP][KCH][8];                                                   // (row 2p, row 2p+1) of every element this lane multiplies
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const float4 a0 = *reinterpret_cast<const float4*>(&xsh[2 * q][lane * 8 + 512 * c]);
+            const float4 a1 = *reinterpret_cast<const float4*>(&xsh[2 * q][lane * 8 + 512 * c + 4]);
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (2 * q + 1 < NB) {
+                b0 = *reinterpret_cast<const float4*>(&xsh[2 * q + 1][lane * 8 + 512 * c]);
+                b1 = *reinterpret_cast<const float4*>(&xsh[2 * q + 1][lane * 8 + 512 * c + 4]);
+            }
+            xp[q][c][0] = (csm_f2){a0.x, b0.x}; xp[q][c][1] = (csm_f2){a0.y, b0.y}; xp[q][c][2] = (csm_f2){a0.z, b0.z}; xp[q][c][3] = (csm_f2){a0.w, b0.w};
+            xp[q][c][4] = (csm_f2){a1.x, b1.x}; xp[q][c][5] = (csm_f2){a1.y, b1.y}; xp[q][c][6] = (csm_f2){a1.z, b1.z}; xp[q][c][7] = (csm_f2){a1.w, b1.w};
+        }
+    csm_f2 acc[RW][NP];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) acc[r][q] = (csm_f2){0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            float wf[8];
+            unpack8(wq[r][c], wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) acc[r][q] = __builtin_elementwise_fma((csm_f2){wf[j], wf[j]}, xp[q][c][j], acc[r][q]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float a0 = (b & 1) ? acc[0][b >> 1].y : acc[0][b >> 1].x;
+        float v;
+        if constexpr (SWIGLU) {
+            const float a1 = (b & 1) ? acc[1][b >> 1].y : acc[1][b >> 1].x;
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+            float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            t += lane_xor<16>(t); t += lane_xor<8>(t); t += lane_xor<4>(t); t += lane_xor<2>(t); t += lane_xor<1>(t);
+            const float gs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+            const float us = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 32));
+            const float g = bf2f(f2bf(gs)), u = bf2f(f2bf(us));
+            v = silu(g) * u;
+        } else {
+            v = wave_sum(a0);
+        }
+        if (lane == 0 && live) {
+            if (R) v += bf2f(R[(size_t)b * ldy + n]);
+            if constexpr (sizeof(OutT) == 2) y[(size_t)b * ldy + n] = f2bf(v);
+            else y[(size_t)b * ldy + n] = v;
+        }
+    }
 }
 
 // y[b][n] = sum_k x[b][k] * W[k][n]  (weights stored K-major, e.g. audio_head[i] = [d'][V]): a thread owns 8 columns.
@@ -1056,9 +1182,10 @@ extern "C" int csm_decode_stamps(unsigned long long* host, int max_records) {
 #endif
 // (g_gemv_rpw: gate/up pairs per wave in the depth decoder's w13 product.  Measured at 1 / 2 / 4: 207.5 / 207.5 / 204 frames/s -
 //  that launch streams 32 MB and is bound by its loads, not by the per-wave normalisation: one pair per wave stays the default)
-static int g_gemv_reg = 1, g_gemv_nt = 1, g_gemv_rpw = 1;       // csm_set_decode_tuning (A/B: tools/probes)
+static int g_gemv_reg = 1, g_gemv_nt = 1, g_gemv_rpw = 1, g_gemv_regn = 1;       // csm_set_decode_tuning (A/B: tools/probes)
 extern "C" int csm_set_decode_tuning(int key, int value) {
-    if (key == 0) g_gemv_reg = value; else if (key == 1) g_gemv_nt = value; else if (key == 2) g_gemv_rpw = value; else return 1;
+    if (key == 0) g_gemv_reg = value; else if (key == 1) g_gemv_nt = value; else if (key == 2) g_gemv_rpw = value;
+    else if (key == 3) g_gemv_regn = value; else return 1;
     return 0;
 }
 static int gemv_launch(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
@@ -1091,6 +1218,20 @@ static int gemv_launch(const void* x, const void* W, void* y, const void* residu
         else { if (nt) LK(bf16_t, false, true); else LK(bf16_t, false, false); }
 #undef LK
 #undef LR
+        CSM_CHECK_LAUNCH("csm_gemv_bf16");
+        return 0;
+    }
+    if (B >= 2 && g_gemv_reg && g_gemv_regn && (K == 1024 || K == 2048)) {
+        // two to four batch rows, x in registers (gemv_regn_kernel)
+        const int gridn = (no + 3) / 4;
+        const bool nt = g_gemv_nt && K == 2048;
+#define LN(KCH, NB, T, SW, NT_) hipLaunchKernelGGL((gemv_regn_kernel<KCH, NB, T, SW, NT_>), dim3(gridn), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset)
+#define LNB(KCH, T, SW, NT_) do { if (B == 2) LN(KCH, 2, T, SW, NT_); else if (B == 3) LN(KCH, 3, T, SW, NT_); else LN(KCH, 4, T, SW, NT_); } while (0)
+#define LNK(T, SW) do { if (K == 1024) LNB(2, T, SW, false); else if (nt) LNB(4, T, SW, true); else LNB(4, T, SW, false); } while (0)
+        if (swiglu) LNK(bf16_t, true); else if (out_f32) LNK(float, false); else LNK(bf16_t, false);
+#undef LNK
+#undef LNB
+#undef LN
         CSM_CHECK_LAUNCH("csm_gemv_bf16");
         return 0;
     }

@@ -214,7 +214,8 @@ int csm_sample_topk(const float* logits, const float* q, int* out, int rows, int
  * y[b][n] = sum_k x[b][k] W[n][k] (+ residual[b][n]), B <= 4 (weight-streaming matrix-vector product) */
 /* tuning switches for A/B runs (since ABI 3): key 0 = one-row products keep x in registers (no LDS copy, no barrier; default 1),
  * key 1 = the 2048-wide stack's weights are loaded non-temporally in decode (default 1),
- * key 2 = gate/up pairs per wave in the depth decoder's w13 product (1, 2 or 4; default 1: measured equal or slower above) */
+ * key 2 = gate/up pairs per wave in the depth decoder's w13 product (1, 2 or 4; default 1: measured equal or slower above),
+ * key 3 = two to four batch rows: K = 1024 / 2048 products keep every row of x in registers (default 1; 0 = the LDS kernel) */
 int csm_set_decode_tuning(int key, int value);
 int csm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int B, int N, int K, int ldw, int ldx, int ldy,
                   int out_f32, csm_stream_t stream);

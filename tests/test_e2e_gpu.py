@@ -689,6 +689,46 @@ def test_fused_decode_kernels_match_their_parts(dev):
         assert torch.equal(o1, o2), "fused rope + append + attention"
 
 
+def test_batched_matrix_vector_kernels_match_single_row(dev):
+    """Round 4: two to four batch rows through gemv_regn_kernel (every row of x in registers, two rows per packed multiply-add) -
+    every row bit-equal to the one-row launch on that row AND to the LDS kernel it replaces (csm_set_decode_tuning(3, 0)), for
+    both widths it takes (K = 1024, 2048), plain / residual / RMSNorm prologue / SwiGLU / fp32 output / rows gathered from a
+    table; K = 8192 (not taken) stays consistent too.  Batched generation equals single generation only because of this."""
+    from csm.hip import ops
+    g = torch.Generator().manual_seed(77)
+    for K, N in ((1024, 1536), (2048, 1024), (8192, 512)):
+        W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(dev)
+        w = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+        table = torch.randn(64, K, generator=g).to(BF).to(dev)
+        for B in (2, 3, 4):
+            x = torch.randn(B, K, generator=g).to(BF).to(dev)
+            R = torch.randn(B, N, generator=g).to(BF).to(dev)
+            idx = torch.randint(0, 32, (B,), generator=g).to(torch.int32).to(dev)
+
+            def run_all(xb, Rb, idxb, Bn):
+                outs = []
+                y = torch.empty(Bn, N, dtype=BF, device=dev); ops.gemv(xb, W, y); outs.append(y)
+                y = torch.empty(Bn, N, dtype=BF, device=dev); ops.gemv(xb, W, y, residual=Rb); outs.append(y)
+                y = torch.empty(Bn, N, dtype=BF, device=dev); ops.gemv_ex(xb, W, y, residual=Rb, norm_scale=w, eps=1e-5); outs.append(y)
+                y = torch.empty(Bn, N // 2, dtype=BF, device=dev); ops.gemv_ex(xb, W, y, norm_scale=w, eps=1e-5, swiglu=True); outs.append(y)
+                y = torch.empty(Bn, N, dtype=torch.float32, device=dev); ops.gemv_ex(xb, W, y, norm_scale=w, eps=1e-5); outs.append(y)
+                y = torch.empty(Bn, N, dtype=BF, device=dev); ops.gemv_ex(table, W, y, row_index=idxb, row_offset=7); outs.append(y)
+                return outs
+
+            new = run_all(x, R, idx, B)
+            try:
+                ops.lib.csm_set_decode_tuning(3, 0)
+                old = run_all(x, R, idx, B)
+            finally:
+                ops.lib.csm_set_decode_tuning(3, 1)
+            for i, (a_, b_) in enumerate(zip(new, old)):
+                assert torch.equal(a_, b_), f"K={K} B={B} form {i}: register kernel vs LDS kernel"
+            for r in range(B):
+                one = run_all(x[r:r + 1].contiguous(), R[r:r + 1].contiguous(), idx[r:r + 1].contiguous(), 1)
+                for i, (a_, b_) in enumerate(zip(new, one)):
+                    assert torch.equal(a_[r:r + 1], b_), f"K={K} B={B} row {r} form {i}: batched vs single"
+
+
 def test_decoder_attention_fused_into_output_projection(dev):
     """csm_gemv_attn_bf16 (a depth-decoder layer's rope + cache append + attention + output projection + residual in one
     launch) against the two launches it replaces, csm_attn_decode_rope + csm_gemv_bf16, at the decoder's own geometry (8 q /
