@@ -541,7 +541,9 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(const bf16_t* __restrict_
 // 2048; K = 8192 stays with gemv_kernel.  Every (row, output) accumulator sees gemv_kernel's products in gemv_kernel's order:
 // bit-identical per row to the one-row kernels (test_batched_matrix_vector_kernels_match_single_row).
 typedef float csm_f2 __attribute__((ext_vector_type(2)));
-template <int KCH, int NB, typename OutT, bool SWIGLU, bool NT>
+// SC = chunks per segment: K = 8192 (KCH = 16) walks x in four segments of four chunks (the fp32 rows stay in LDS, 128 KB at four
+// rows; a segment's elements are in registers while its weight chunks are multiplied), K <= 2048 is one segment.
+template <int KCH, int NB, typename OutT, bool SWIGLU, bool NT, int SC = KCH>
 __global__ __launch_bounds__(256) void gemv_regn_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, OutT* __restrict__ y,
                                                         const bf16_t* __restrict__ R, int N, int ldw, int ldx, int ldy,
                                                         const bf16_t* __restrict__ norm_w, float eps, const int* __restrict__ row_index,
@@ -564,7 +566,8 @@ __global__ __launch_bounds__(256) void gemv_regn_kernel(const bf16_t* __restrict
         }
     // wave b < NB prepares row b of x (RMSNorm as a wave reduction, rounded to bf16 as gemv_kernel's LDS copy is) and publishes it
     // as fp32; ONE barrier; every lane then takes the elements it multiplies, two rows per register pair
-    __shared__ __attribute__((aligned(16))) float xsh[NB][K];
+    extern __shared__ __attribute__((aligned(16))) char smem_n[];
+    float (*xsh)[K] = reinterpret_cast<float (*)[K]>(smem_n);                // [NB][K]
     const int wv = threadIdx.x >> 6;
     if (wv < NB) {
         const int b = wv;
@@ -601,36 +604,41 @@ __global__ __launch_bounds__(256) void gemv_regn_kernel(const bf16_t* __restrict
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (LDS only: the weight rows stay in flight)
-    csm_f2 xp[NP][KCH][8];                                                   // (row 2p, row 2p+1) of every element this lane multiplies
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            const float4 a0 = *reinterpret_cast<const float4*>(&xsh[2 * q][lane * 8 + 512 * c]);
-            const float4 a1 = *reinterpret_cast<const float4*>(&xsh[2 * q][lane * 8 + 512 * c + 4]);
-            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-            if (2 * q + 1 < NB) {
-                b0 = *reinterpret_cast<const float4*>(&xsh[2 * q + 1][lane * 8 + 512 * c]);
-                b1 = *reinterpret_cast<const float4*>(&xsh[2 * q + 1][lane * 8 + 512 * c + 4]);
-            }
-            xp[q][c][0] = (csm_f2){a0.x, b0.x}; xp[q][c][1] = (csm_f2){a0.y, b0.y}; xp[q][c][2] = (csm_f2){a0.z, b0.z}; xp[q][c][3] = (csm_f2){a0.w, b0.w};
-            xp[q][c][4] = (csm_f2){a1.x, b1.x}; xp[q][c][5] = (csm_f2){a1.y, b1.y}; xp[q][c][6] = (csm_f2){a1.z, b1.z}; xp[q][c][7] = (csm_f2){a1.w, b1.w};
-        }
     csm_f2 acc[RW][NP];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int q = 0; q < NP; ++q) acc[r][q] = (csm_f2){0.f, 0.f};
+    static_assert(KCH % SC == 0, "whole segments");
 #pragma unroll
-    for (int c = 0; c < KCH; ++c) {
+    for (int sg = 0; sg < KCH / SC; ++sg) {
+        csm_f2 xp[NP][SC][8];                                                // (row 2p, row 2p+1) of the segment's elements this lane multiplies
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            float wf[8];
-            unpack8(wq[r][c], wf);
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int cc = 0; cc < SC; ++cc) {
+                const int c = sg * SC + cc;
+                const float4 a0 = *reinterpret_cast<const float4*>(&xsh[2 * q][lane * 8 + 512 * c]);
+                const float4 a1 = *reinterpret_cast<const float4*>(&xsh[2 * q][lane * 8 + 512 * c + 4]);
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                if (2 * q + 1 < NB) {
+                    b0 = *reinterpret_cast<const float4*>(&xsh[2 * q + 1][lane * 8 + 512 * c]);
+                    b1 = *reinterpret_cast<const float4*>(&xsh[2 * q + 1][lane * 8 + 512 * c + 4]);
+                }
+                xp[q][cc][0] = (csm_f2){a0.x, b0.x}; xp[q][cc][1] = (csm_f2){a0.y, b0.y}; xp[q][cc][2] = (csm_f2){a0.z, b0.z}; xp[q][cc][3] = (csm_f2){a0.w, b0.w};
+                xp[q][cc][4] = (csm_f2){a1.x, b1.x}; xp[q][cc][5] = (csm_f2){a1.y, b1.y}; xp[q][cc][6] = (csm_f2){a1.z, b1.z}; xp[q][cc][7] = (csm_f2){a1.w, b1.w};
+            }
 #pragma unroll
-                for (int q = 0; q < NP; ++q) acc[r][q] = __builtin_elementwise_fma((csm_f2){wf[j], wf[j]}, xp[q][c][j], acc[r][q]);
+        for (int cc = 0; cc < SC; ++cc) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                float wf[8];
+                unpack8(wq[r][sg * SC + cc], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) acc[r][q] = __builtin_elementwise_fma((csm_f2){wf[j], wf[j]}, xp[q][cc][j], acc[r][q]);
+            }
         }
     }
 #pragma unroll
@@ -1221,14 +1229,18 @@ static int gemv_launch(const void* x, const void* W, void* y, const void* residu
         CSM_CHECK_LAUNCH("csm_gemv_bf16");
         return 0;
     }
-    if (B >= 2 && g_gemv_reg && g_gemv_regn && (K == 1024 || K == 2048)) {
+    if (B >= 2 && g_gemv_reg && g_gemv_regn && (K == 1024 || K == 2048 || (K == 8192 && !swiglu && !out_f32))) {
         // two to four batch rows, x in registers (gemv_regn_kernel)
         const int gridn = (no + 3) / 4;
-        const bool nt = g_gemv_nt && K == 2048;
-#define LN(KCH, NB, T, SW, NT_) hipLaunchKernelGGL((gemv_regn_kernel<KCH, NB, T, SW, NT_>), dim3(gridn), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset)
-#define LNB(KCH, T, SW, NT_) do { if (B == 2) LN(KCH, 2, T, SW, NT_); else if (B == 3) LN(KCH, 3, T, SW, NT_); else LN(KCH, 4, T, SW, NT_); } while (0)
-#define LNK(T, SW) do { if (K == 1024) LNB(2, T, SW, false); else if (nt) LNB(4, T, SW, true); else LNB(4, T, SW, false); } while (0)
-        if (swiglu) LNK(bf16_t, true); else if (out_f32) LNK(float, false); else LNK(bf16_t, false);
+        const bool nt = g_gemv_nt && (K == 2048 || (K == 8192 && N == 2048));
+        const size_t ldsn = (size_t)B * K * sizeof(float);
+#define LN(KCH, NB, T, SW, NT_, SC_) do { auto kf = gemv_regn_kernel<KCH, NB, T, SW, NT_, SC_>;                                       \
+            if (ldsn > 65536) { static bool done_ = false; if (!done_) { (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn); done_ = true; } } \
+            hipLaunchKernelGGL(kf, dim3(gridn), dim3(256), ldsn, stream, (const bf16_t*)x, (const bf16_t*)W, (T*)y, (const bf16_t*)residual, N, ldw, ldx, ldy, (const bf16_t*)norm_w, eps, row_index, row_offset); } while (0)
+#define LNB(KCH, T, SW, NT_, SC_) do { if (B == 2) LN(KCH, 2, T, SW, NT_, SC_); else if (B == 3) LN(KCH, 3, T, SW, NT_, SC_); else LN(KCH, 4, T, SW, NT_, SC_); } while (0)
+#define LNK(T, SW) do { if (K == 1024) LNB(2, T, SW, false, 2); else if (nt) LNB(4, T, SW, true, 4); else LNB(4, T, SW, false, 4); } while (0)
+        if (K == 8192) { if (nt) LNB(16, bf16_t, false, true, 4); else LNB(16, bf16_t, false, false, 4); }
+        else if (swiglu) LNK(bf16_t, true); else if (out_f32) LNK(float, false); else LNK(bf16_t, false);
 #undef LNK
 #undef LNB
 #undef LN
