@@ -843,7 +843,7 @@ class _DecodeStack:
                 ops.gemv_attn(self.qkv, self.k[i], self.v[i], self.pos, table, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, cur,
                               H, KV, hd, pos_host=self.pos_host)
             else:
-                ops.attn_decode_rope(self.qkv, self.k[i], self.v[i], self.o, self.pos, table, H, KV, hd)
+                ops.attn_decode_rope(self.qkv, self.k[i], self.v[i], self.o, self.pos, table, H, KV, hd, pos_host=self.pos_host)
                 ops.gemv(self.o, st.w(f"layers.{i}.attn.output_proj.weight"), self.h, residual=cur)
             ops.gemv_ex(self.h, st.w(f"layers.{i}.mlp.w13"), self.act, norm_scale=st.w(f"layers.{i}.mlp_norm.scale"), eps=c.norm_eps,
                         swiglu=True)
@@ -955,8 +955,19 @@ class DecodeState:
             self.fill_noise(noise)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.out_static = self.e._decode_frame_body(self, self.in_tok, self.in_msk, temperature, topk)
+            # No cyclic garbage collection while the stream is capturing: a collection that happens to run inside the ~700
+            # launches may finalise objects whose destructors call the runtime (an older model's captured graph, events) - not
+            # allowed during capture, the process aborts (seen once a test run's allocation pattern moved a collection in
+            # there).  torch.cuda.graph() collects before it starts capturing; reference-counted frees are unaffected.
+            import gc
+            gc_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):
+                    self.out_static = self.e._decode_frame_body(self, self.in_tok, self.in_msk, temperature, topk)
+            finally:
+                if gc_on:
+                    gc.enable()
             self.graph, self.graph_key = g, key
             g.replay()
             return self.out_static.clone()

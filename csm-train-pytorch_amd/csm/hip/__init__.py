@@ -79,6 +79,7 @@ _SIGS = {
     "csm_attn_decode_rope": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_gemv_attn_bf16": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_gemv_attn_at_bf16": ([_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "csm_attn_decode_rope_at": ([_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_kv_append": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_attn_decode": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "csm_sample_topk": ([_p, _p, _p, _i, _i, _i, _i, _f, _p], _i),

@@ -414,10 +414,16 @@ def gemv_ex(x, W, y, residual=None, norm_scale=None, eps=1e-5, swiglu=False, row
     return y
 
 
-def attn_decode_rope(qkv, kcache, vcache, out, pos_i32, table, H, KV, HD):
-    """rope(q, new k) + append(new k, v) + one-position attention against the caches, one launch."""
+def attn_decode_rope(qkv, kcache, vcache, out, pos_i32, table, H, KV, HD, pos_host=None):
+    """rope(q, new k) + append(new k, v) + one-position attention against the caches, one launch.  ``pos_host``: the position all
+    rows share, as a host integer (the depth decoder's step; HD = 128, H = 4 KV, S_max <= 32): the launch that issues every load
+    of its prologue at once."""
     B, _, S_max, _ = kcache.shape
     assert table.dtype == torch.float32 and table.is_contiguous()
+    if pos_host is not None and HD == 128 and H == 4 * KV and S_max <= 32 and out.is_contiguous():
+        check(lib.csm_attn_decode_rope_at(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), int(pos_host),
+                                          table.data_ptr(), B, H, KV, HD, S_max, qkv.stride(0), _stream()), "csm_attn_decode_rope_at")
+        return out
     check(lib.csm_attn_decode_rope(qkv.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), pos_i32.data_ptr(),
                                    table.data_ptr(), B, H, KV, HD, S_max, qkv.stride(0), _stream()), "csm_attn_decode_rope")
     return out

@@ -1173,6 +1173,138 @@ __global__ __launch_bounds__(512) void gemv_attn_at_kernel(const bf16_t* __restr
     STAMP_FLUSH(200);
 }
 
+// The depth decoder's attention for two to four utterances (round 4; generate_batch), position known on the host: the scores and
+// P.V phases of gemv_attn_at_kernel as a launch of their own - one workgroup per (batch row, kv head), its four q heads on four
+// waves - where the fused form would make every workgroup of the output projection recompute all rows' attention (measured in
+// round 3: slower from two rows on).  Same loads-at-once prologue, same coalesced key / value images, same arithmetic as
+// attn_decode_kernel<128> operation for operation: bit-identical.  H = 4 KV, S_max <= 32.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_at_kernel(const bf16_t* __restrict__ qkv, bf16_t* kc, bf16_t* vc, bf16_t* __restrict__ out,
+                                                             int p, const float* __restrict__ table, int H, int KV, int S_max, int ld,
+                                                             float scale) {
+    static_assert(HD == 128, "lane = column pair in the P.V phase");
+    constexpr int KROW = HD * 2 + 16, VROW = HD * 2;
+    __shared__ __attribute__((aligned(16))) float qs[4][HD];
+    __shared__ float pw[4][32], psum[4];
+    __shared__ __attribute__((aligned(16))) char ks[32 * KROW];
+    __shared__ __attribute__((aligned(16))) char vs[32 * VROW];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = p + 1;
+    const bf16_t* row = qkv + (size_t)b * ld;
+    bf16_t* Kc = kc + ((size_t)b * KV + kvh) * S_max * HD;
+    bf16_t* Vc = vc + ((size_t)b * KV + kvh) * S_max * HD;
+    // ---- every load at once: RoPE inputs of the group's four q heads and its k head (5 x 64 pairs over 256 threads: two rounds),
+    //      the new value beside the k pairs, the cached rows as contiguous 16-byte chunks (two per thread and image)
+    float rc[2], rs[2], rx0[2], rx1[2];
+    uint32_t rv[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int it = threadIdx.x + 256 * t;
+        rc[t] = rs[t] = rx0[t] = rx1[t] = 0.f;
+        if (it < 5 * (HD / 2)) {
+            const int i = it % (HD / 2), hh = it / (HD / 2);                 // hh < 4: q head 4 kvh + hh; hh == 4: the k head
+            const float2 cs = *reinterpret_cast<const float2*>(table + ((size_t)p * (HD / 2) + i) * 2);
+            const int col = (hh < 4 ? (4 * kvh + hh) : (H + kvh)) * HD + 2 * i;
+            const uint32_t xx = *reinterpret_cast<const uint32_t*>(row + col);
+            if (hh == 4) rv[t] = *reinterpret_cast<const uint32_t*>(row + (H + KV + kvh) * HD + 2 * i);
+            rc[t] = cs.x; rs[t] = cs.y; rx0[t] = __uint_as_float(xx << 16); rx1[t] = __uint_as_float(xx & 0xffff0000u);
+        }
+    }
+    U4 kg[2] = {}, vg[2] = {};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = threadIdx.x + 256 * t;
+        if (ch < p * (HD / 8)) {
+            kg[t] = *reinterpret_cast<const U4*>(Kc + (size_t)ch * 8);
+            vg[t] = *reinterpret_cast<const U4*>(Vc + (size_t)ch * 8);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int it = threadIdx.x + 256 * t;
+        if (it < 5 * (HD / 2)) {
+            const int i = it % (HD / 2), hh = it / (HD / 2);
+            float y0 = rx0[t], y1 = rx1[t];
+            rope_rot(y0, y1, rc[t], rs[t]);
+            const bf16_t r0 = f2bf(y0), r1 = f2bf(y1);
+            if (hh < 4) {
+                qs[hh][2 * i] = bf2f(r0); qs[hh][2 * i + 1] = bf2f(r1);
+            } else {
+                const uint32_t kk = (uint32_t)r0 | ((uint32_t)r1 << 16);
+                *reinterpret_cast<uint32_t*>(ks + (size_t)p * KROW + 4 * i) = kk;
+                *reinterpret_cast<uint32_t*>(vs + (size_t)p * VROW + 4 * i) = rv[t];
+                *reinterpret_cast<uint32_t*>(Kc + (size_t)p * HD + 2 * i) = kk;        // (row p: no load above reads it)
+                *reinterpret_cast<uint32_t*>(Vc + (size_t)p * HD + 2 * i) = rv[t];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = threadIdx.x + 256 * t;
+        if (ch < p * (HD / 8)) {
+            const int r_ = ch / (HD / 8), c_ = ch % (HD / 8);
+            *reinterpret_cast<U4*>(ks + (size_t)r_ * KROW + c_ * 16) = kg[t];
+            *reinterpret_cast<U4*>(vs + (size_t)r_ * VROW + c_ * 16) = vg[t];
+        }
+    }
+    lds_barrier();
+    // ---- scores + softmax: waves 0, 1 - two heads per wave in lane halves (see gemv_attn_at_kernel)
+    if (wave < 2) {
+        const int hh = 2 * wave + (lane >> 5), key = lane & 31;
+        const float* q = qs[hh];
+        float d = 0.f;
+        if (key < n) {
+            const char* krow = ks + (size_t)key * KROW;
+#pragma unroll
+            for (int c = 0; c < HD / 8; ++c) {
+                float kf[8];
+                unpack8(*reinterpret_cast<const U4*>(krow + c * 16), kf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += q[c * 8 + j] * kf[j];
+            }
+            d *= scale;
+        }
+        float mx = key < n ? d : -INFINITY;
+        mx = fmaxf(mx, lane_xor<16>(mx)); mx = fmaxf(mx, lane_xor<8>(mx)); mx = fmaxf(mx, lane_xor<4>(mx));
+        mx = fmaxf(mx, lane_xor<2>(mx)); mx = fmaxf(mx, lane_xor<1>(mx));
+        const float pr = key < n ? __expf(d - mx) : 0.f;
+        float sum = pr;
+        sum += lane_xor<16>(sum); sum += lane_xor<8>(sum); sum += lane_xor<4>(sum); sum += lane_xor<2>(sum); sum += lane_xor<1>(sum);
+        pw[hh][key] = pr;
+        if (key == 0) psum[hh] = sum;
+    }
+    lds_barrier();
+    // ---- P.V: wave = head of the group, lane = column pair, the reference's summation tree (see gemv_attn_at_kernel)
+    {
+        const float* ph = pw[wave];
+        const char* vcol = vs + lane * 4;
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a0[4], a1[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                a0[g4] = 0.f; a1[g4] = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int s_ = 4 * r + g4 + 16 * u;
+                    if (s_ < n) {
+                        const uint32_t vv = *reinterpret_cast<const uint32_t*>(vcol + (size_t)s_ * VROW);
+                        const float ps = ph[s_];
+                        a0[g4] = __builtin_fmaf(ps, __uint_as_float(vv << 16), a0[g4]);
+                        a1[g4] = __builtin_fmaf(ps, __uint_as_float(vv & 0xffff0000u), a1[g4]);
+                    }
+                }
+            }
+            o0 += (a0[0] + a0[1]) + (a0[2] + a0[3]);
+            o1 += (a1[0] + a1[1]) + (a1[2] + a1[3]);
+        }
+        const float sum = psum[wave];
+        *reinterpret_cast<uint32_t*>(out + (size_t)b * H * HD + (4 * kvh + wave) * HD + 2 * lane) =
+            (uint32_t)f2bf(o0 / sum) | ((uint32_t)f2bf(o1 / sum) << 16);
+    }
+}
+
 }  // namespace
 
 #ifdef CSM_DECODE_STAMPS
@@ -1311,6 +1443,18 @@ extern "C" int csm_attn_decode(const void* qkv, const void* kcache, const void* 
                                int KV, int HD, int S_max, int ld, hipStream_t stream) {
     return attn_decode_launch(qkv, const_cast<void*>(kcache), const_cast<void*>(vcache), out, pos, nullptr, B, H, KV, HD, S_max, ld,
                               stream);
+}
+
+extern "C" int csm_attn_decode_rope_at(const void* qkv, void* kcache, void* vcache, void* out, int pos, const float* rope_table,
+                                       int B, int H, int KV, int HD, int S_max, int ld, hipStream_t stream) {
+    CSM_REQUIRE(qkv && kcache && vcache && out && rope_table && B > 0, "csm_attn_decode_rope_at: bad arguments");
+    CSM_REQUIRE(HD == 128 && H == 4 * KV && S_max >= 1 && S_max <= 32 && (ld & 7) == 0,
+                "csm_attn_decode_rope_at: unsupported shape (H=%d KV=%d HD=%d S_max=%d: needs HD 128, H = 4 KV, S_max <= 32)", H, KV, HD, S_max);
+    CSM_REQUIRE(pos >= 0 && pos < S_max, "csm_attn_decode_rope_at: position %d outside the cache (%d rows)", pos, S_max);
+    hipLaunchKernelGGL((attn_decode_at_kernel<128>), dim3(KV, B), dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache,
+                       (bf16_t*)out, pos, rope_table, H, KV, S_max, ld, 1.f / sqrtf((float)HD));
+    CSM_CHECK_LAUNCH("csm_attn_decode_rope_at");
+    return 0;
 }
 
 extern "C" int csm_attn_decode_rope(const void* qkv, void* kcache, void* vcache, void* out, const int* pos, const float* rope_table,

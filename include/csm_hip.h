@@ -236,6 +236,10 @@ int csm_gemv_t_bf16(const void* x, const void* W, void* y, int B, int N, int K, 
 int csm_gemv_attn_bf16(const void* qkv, void* kcache, void* vcache, const int* pos, const float* rope_table, const void* W, void* y,
                        const void* residual, int B, int N, int H, int KV, int HD, int S_max, int ld_qkv, int ldw, int ldy,
                        csm_stream_t stream);
+/* csm_attn_decode_rope for rows that share a position the host knows (round 4: the depth decoder's step i of a batch of utterances):
+ * all loads of the prologue at once, coalesced key / value images; HD = 128, H = 4 KV, S_max <= 32; bit-identical to it. */
+int csm_attn_decode_rope_at(const void* qkv, void* kcache, void* vcache, void* out, int pos, const float* rope_table, int B, int H,
+                            int KV, int HD, int S_max, int ld, csm_stream_t stream);
 /* the same for one utterance (B = 1) whose position the host knows (round 4: the depth decoder's step i is always at position i,
  * so a captured frame graph carries it as an argument): every address of the prologue is known at launch and all its loads
  * go out at once.  S_max <= 32, H * HD = 1024; bit-identical to csm_gemv_attn_bf16. */

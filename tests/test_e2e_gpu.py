@@ -760,6 +760,17 @@ def test_decoder_attention_fused_into_output_projection(dev):
             ops.gemv_attn(qkv, k2, v2, pos, table, W, y3, None, H, KV, hd)        # (append again: same bits; no residual)
             ops.gemv(o, W, y1)
             assert torch.equal(y1, y3)
+            if B > 1:
+                # round 4: rows that share a position the host knows (a batch of utterances at decoder step p): the attention-only
+                # launch with all loads at once - output and caches bit-equal to csm_attn_decode_rope at every position
+                for p in range(S_max):
+                    posb = torch.full((B,), p, dtype=torch.int32, device=dev)
+                    k3, v3, k4, v4 = kc.to(dev), vc.to(dev), kc.to(dev), vc.to(dev)
+                    oa, ob = torch.empty(B, H * hd, dtype=BF, device=dev), torch.empty(B, H * hd, dtype=BF, device=dev)
+                    ops.attn_decode_rope(qkv, k3, v3, oa, posb, table, H, KV, hd)
+                    ops.attn_decode_rope(qkv, k4, v4, ob, posb, table, H, KV, hd, pos_host=p)
+                    assert torch.equal(k3, k4) and torch.equal(v3, v4), f"caches, B={B}, host position {p}"
+                    assert torch.equal(oa, ob), f"attention, B={B}, host position {p}"
             if B == 1:
                 # round 4: the launch that takes the position from the host (the depth decoder's step i is at position i) and
                 # issues every load of its prologue at once - every position of a frame, same bits in output and caches
