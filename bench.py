@@ -658,6 +658,12 @@ def main():
                                                   "bytes_per_frame": bytes_frame}}
         except Exception as e:  # noqa: BLE001 - an extra leg must never take the headline line down
             extra["generate_10s"] = {"error": repr(e)}
+        try:
+            gb = generate_bench.run_batch(model, nb=4, frames=125)
+            extra["generate_batch4_10s"] = {"workload": "generate_batch(): 4 utterances x 125 frames decoded together (ragged prompts; "
+                                                        "every row's frames equal the frames it samples alone)", **gb}
+        except Exception as e:  # noqa: BLE001
+            extra["generate_batch4_10s"] = {"error": repr(e)}
 
     if rank == 0:
         if extra:

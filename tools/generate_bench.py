@@ -81,6 +81,25 @@ def run(model, frames=125, repeats=2):
             "x_real_time": round(nfr * 0.08 / dt, 2), "includes": "Mimi encode of the context + prefill + decode frames + Mimi decode"}
 
 
+def run_batch(model, nb=4, frames=125):
+    """generate_batch(): ``nb`` utterances decoded together (ragged prompts, shared weight loads); aggregate frames/s of the second
+    of two runs (the first captures the batch's frame graph)."""
+    dev = model.device
+    gen = Generator(model, text_tokenizer=ByteTokenizer(), audio_tokenizer=make_codec(dev))
+    ctx = [Segment(0, "hello there", torch.randn(5 * 24000, device=dev) * 0.1)]
+    texts = [f"utterance number {i}: the quick brown fox jumps over the lazy dog" for i in range(nb)]
+    ctxs = [ctx if i % 2 == 0 else [] for i in range(nb)]
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        outs = gen.generate_batch(texts, list(range(nb)), ctxs, max_audio_length_ms=80 * frames)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    tot = sum(o.numel() for o in outs) / 1920
+    return {"utterances": nb, "frames": tot, "seconds": round(dt, 4), "frames_per_s_aggregate": round(tot / dt, 1),
+            "x_real_time_aggregate": round(tot * 0.08 / dt, 2)}
+
+
 def main():
     dev = "cuda:0"
     model = Model(csm_1b_args(), device=dev, seed=0)
