@@ -274,6 +274,54 @@ def test_config5_generate_csm1b_125_frames(dev, csm1b):
         m.use_hip_graph, m.use_kv_cache = True, True
 
 
+def test_config5_batched_generation_csm1b_matches_single(dev, csm1b):
+    """generate_batch's kernels at CSM-1B shapes (round 4: two to four rows through the register matrix-vector kernel - K = 1024,
+    2048, 8192 - and the depth decoder's attention with the shared host position): three utterances with prompts of different
+    lengths decoded together sample exactly the frames each samples alone, given the same Exp(1) draws - prefill frame, first
+    decode frame (eager) and the frames replayed from the captured graph."""
+    m = csm1b
+    K, V = m.args.audio_num_codebooks, m.args.audio_vocab_size
+    g = torch.Generator().manual_seed(131)
+    prompts = []
+    for S in (23, 40, 31):
+        tokens = torch.zeros(S, K + 1, dtype=torch.long)
+        mask = torch.zeros(S, K + 1, dtype=torch.bool)
+        n_text = S // 2
+        tokens[:n_text, K] = torch.randint(0, m.args.text_vocab_size, (n_text,), generator=g)
+        mask[:n_text, K] = True
+        tokens[n_text:, :K] = torch.randint(0, 2048, (S - n_text, K), generator=g)
+        mask[n_text:, :K] = True
+        prompts.append((tokens, mask))
+    n_frames = 5
+    noise = [[torch.empty(3, V).exponential_(1.0, generator=g) for _ in range(K)] for _ in range(n_frames)]
+    amask = torch.cat([torch.ones(1, K, dtype=torch.bool), torch.zeros(1, 1, dtype=torch.bool)], 1).unsqueeze(1)
+
+    def run(rows):
+        B = len(rows)
+        m.use_hip_graph, m.use_kv_cache = True, True
+        m.setup_caches(B)
+        m.reset_caches()
+        fr = [m.engine.generate_first_frames([prompts[r][0] for r in rows], [prompts[r][1] for r in rows], 0.9, 50,
+                                             noise=[n[rows] for n in noise[0]])]
+        for f in range(1, n_frames):
+            tok = torch.cat([fr[-1].long().cpu(), torch.zeros(B, 1, dtype=torch.long)], 1).unsqueeze(1)
+            fr.append(m.generate_frame(tok, amask.expand(B, -1, -1), torch.ones(B, 1, dtype=torch.long), 0.9, 50,
+                                       noise=[n[rows] for n in noise[f]]))
+        return torch.stack([x.cpu() for x in fr], 1)                # [B, frames, K]
+
+    try:
+        all3 = run([0, 1, 2])
+        assert all3.shape == (3, n_frames, K)
+        assert m._decode_state.graph is not None, "the later frames went through the captured graph"
+        for r in range(3):
+            assert torch.equal(all3[r:r + 1], run([r])), f"utterance {r}: batched frames differ from the frames it samples alone"
+        pair = run([2, 0])
+        assert torch.equal(pair[0], all3[2]) and torch.equal(pair[1], all3[0]), "two rows, other order"
+        assert not torch.equal(all3[0], all3[1])
+    finally:
+        m.setup_caches(1)
+
+
 def test_config1_lora_trainer_csm1b(dev, tmp_path):
     """BASELINE config 1's plumbing on the device: CSM-1B random-init, a dataset of 2 synthetic text+audio segments per item,
     one epoch of ``CSMLoRATrainer.train`` (get_batch protocol, batch 2), then ``save_model``: returns a float, every step's
