@@ -40,6 +40,8 @@ GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
 DEFER_ATTN_DW = int(_os.environ.get("CSM_DEFER_ATTN_DW", "3"))
 # the RMSNorm scale gradients' column sums of a layer (and of the layers whose attention gradients are deferred) in one launch
 DEFER_NORM_DW = _os.environ.get("CSM_DEFER_NORM_DW", "1") == "1"
+# embedding backward: one sort of (row, source) keys instead of a stable argsort + two gathers (A/B: 0 = the latter)
+EMB_KEYSORT = _os.environ.get("CSM_EMB_KEYSORT", "1") == "1"
 # the depth decoder's fused attention + output projection takes its position as a launch argument (A/B: 0 = from device memory)
 DECODE_POS_HOST = _os.environ.get("CSM_DECODE_POS_HOST", "1") == "1"
 # LoRA groups ride on the frozen projections' GEMMs as K-extension operands (training/lora.py); 0 = per-adapter products
@@ -387,6 +389,7 @@ class Engine:
         self.param_hook = None
         # a list here makes the cache-free generate path append the logits [B, V] every code is drawn from (parity tests)
         self.capture_logits = None
+        self._consts = {}               # index tensors that depend on shapes only (built once, reused every step)
 
     def _need(self, group=None, layer=None):
         if self.param_hook is not None:
@@ -623,18 +626,36 @@ class Engine:
         n_rows = TV + K * V
         tk, mk = s["tk"], s["mk"]
         M = tk.shape[0]
-        slot = torch.arange(K + 1, device=dev)
-        rows = torch.where(slot < K, TV + tk + slot * V, tk)                 # [M, K+1] combined row id
-        rows = torch.where(mk.bool(), rows, torch.full_like(rows, n_rows))   # masked-out slots -> padding id
-        src = torch.arange(M, device=dev).unsqueeze(1).expand(M, K + 1)
-        rows, src = rows.reshape(-1), src.reshape(-1)
+        # shape-only index tensors (slot offsets, source ids) are built once per shape, not once per step
+        ck = ("embbwd", M, K, V, TV)
+        c = self._consts.get(ck)
+        if c is None:
+            slot = torch.arange(K + 1, device=dev)
+            c = self._consts[ck] = dict(off=torch.where(slot < K, TV + slot * V, torch.zeros_like(slot)),            # [K+1] row offset of a slot
+                                        src=torch.arange(M, device=dev).unsqueeze(1).expand(M, K + 1).reshape(-1).contiguous())
+        rows = torch.where(mk.bool(), tk + c["off"], torch.full_like(tk, n_rows)).reshape(-1)   # [M (K+1)]; masked-out slots -> padding id
+        src = c["src"]
+        n_src = M
         if dseq is not None:
             codes, N = s["dec"]["codes"], s["dec"]["N"]
-            r2 = TV + codes[:, :K - 1] + torch.arange(K - 1, device=dev) * V                      # [N, K-1]
-            s2 = M + torch.arange(N, device=dev).unsqueeze(1) * K + torch.arange(1, K, device=dev)
-            rows, src = torch.cat([rows, r2.reshape(-1)]), torch.cat([src, s2.reshape(-1)])
-        order = torch.argsort(rows, stable=True)
-        ops.embed_bwd_sorted(rows[order].contiguous(), src[order].contiguous(), dh0, dseq,
+            dk = ("embbwd_dec", M, N, K, V, TV)
+            d = self._consts.get(dk)
+            if d is None:
+                d = self._consts[dk] = dict(off=TV + torch.arange(K - 1, device=dev) * V,
+                                            src=(M + torch.arange(N, device=dev).unsqueeze(1) * K + torch.arange(1, K, device=dev)).reshape(-1))
+            rows = torch.cat([rows, (codes[:, :K - 1] + d["off"]).reshape(-1)])
+            src = torch.cat([src, d["src"]])
+            n_src = M + N * K
+        if n_src <= (1 << 20) and EMB_KEYSORT:
+            # (row, source) pairs are unique, so ONE key sort gives the order a stable sort by row gives (sources ascend within a
+            # row exactly as the occurrences were listed) - a radix sort of 64-bit keys instead of a stable merge sort (18 launches)
+            # plus two gathers
+            key = torch.sort((rows << 20) | src).values
+            rows_s, src_s = key >> 20, key & ((1 << 20) - 1)
+        else:
+            order = torch.argsort(rows, stable=True)
+            rows_s, src_s = rows[order].contiguous(), src[order].contiguous()
+        ops.embed_bwd_sorted(rows_s, src_s, dh0, dseq,
                              m.block("text_embeddings.weight", True), m.block("audio_embeddings.weight", True))
 
     # -------------------------------------------------------------------------------------------- generation
