@@ -40,6 +40,8 @@ GROUP_ATTN_DW = _os.environ.get("CSM_GROUP_ATTN_DW", "1") == "1"
 DEFER_ATTN_DW = int(_os.environ.get("CSM_DEFER_ATTN_DW", "3"))
 # the RMSNorm scale gradients' column sums of a layer (and of the layers whose attention gradients are deferred) in one launch
 DEFER_NORM_DW = _os.environ.get("CSM_DEFER_NORM_DW", "1") == "1"
+# the depth decoder's random frame subset is drawn on the host (A/B: 0 = device randperm)
+ROWS_ON_HOST = _os.environ.get("CSM_ROWS_ON_HOST", "1") == "1"
 # embedding backward: one sort of (row, source) keys instead of a stable argsort + two gathers (A/B: 0 = the latter)
 EMB_KEYSORT = _os.environ.get("CSM_EMB_KEYSORT", "1") == "1"
 # the depth decoder's fused attention + output projection takes its position as a launch argument (A/B: 0 = from device memory)
@@ -489,7 +491,17 @@ class Engine:
             if t0 is not None:
                 r = r[t0[r] >= 0]
             return r.to(torch.int32).contiguous()
-        allr = (torch.arange(B, device=dev)[:, None] * S + torch.arange(S - 1, device=dev)[None, :]).reshape(-1)
+        if t0 is None and self.m.acoustic_mode != "all" and ROWS_ON_HOST:
+            # a random subset of all frames: drawn on the host (torch's CPU generator) and copied over - one small copy instead of
+            # ~20 launches of device randperm / sort / index kernels in front of the depth decoder
+            n_all = B * (S - 1)
+            n = max(1, int(round(n_all * self.m.acoustic_fraction)))
+            perm = torch.randperm(n_all)[:n].sort().values
+            return ((perm // (S - 1)) * S + perm % (S - 1)).to(torch.int32).to(dev, non_blocking=True)
+        ck = ("allr", B, S)
+        allr = self._consts.get(ck)
+        if allr is None:
+            allr = self._consts[ck] = (torch.arange(B, device=dev)[:, None] * S + torch.arange(S - 1, device=dev)[None, :]).reshape(-1)
         if t0 is not None:
             allr = allr[t0[allr] >= 0]
             if allr.numel() == 0:
